@@ -1,0 +1,678 @@
+"""CPU oracle for the acoustic-model hot path of gunkisu/asr  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement (float64 by default) of the reference's Theano/Lasagne step
+functions, their BPTT, the framewise softmax-CE loss and the Adam update.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it; the product
+package `asr_amd` never does.
+
+PARITY UNPINNED: the reference ships no golden vectors, fixtures or known-answer tests for this
+path and Theano/Lasagne are not importable in this image, so the oracle
+cannot be checked against outputs of the reference itself.  It is instead pinned by (1) a line-by
+-line torch float64 transliteration of the reference step functions differentiated with torch
+autograd (tests/test_oracle_autograd.py) and (2) central finite differences.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+
+Third-party semantics restated here (Theano / Lasagne, not vendored in the reference, no version
+pin exists):  `theano.gradient.grad_clip(x, -c, c)` = identity forward, elementwise clip of the
+incoming gradient backward, skipped when c == 0;  `T.switch(m, a, b)` routes gradient to `a` where
+m != 0 else to `b`;  `T.var` = population variance;  `theano.scan(go_backwards=True)` iterates
+t = T-1..0 over the padded array;  Lasagne `DenseLayer` = x.W + b, W (in, out).
+"""
+import numpy as np
+
+EPS = float(np.finfo(np.float32).eps)   # libs/lhuclstm_layers.py:13-14 (floatX = float32)
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _clip(g, c):
+    return np.clip(g, -c, c) if c else g
+
+
+# --------------------------------------------------------------------------------------------
+# layer norm  (libs/lhuclstm_layers.py:16-21, libs/lasagne_libs/recurrent_layers.py:10-15,27-32)
+# --------------------------------------------------------------------------------------------
+def ln_fwd(x, alpha, beta=None):
+    """y = alpha * (x - mean) / sqrt(var + eps) [+ beta]; alpha/beta are (n,) or per-sample (B,n)."""
+    mu = x.mean(axis=1, keepdims=True)
+    var = x.var(axis=1, keepdims=True)
+    s = np.sqrt(var + EPS)
+    xh = (x - mu) / s
+    y = alpha * xh
+    if beta is not None:
+        y = y + beta
+    return y, (xh, s)
+
+
+def ln_bwd(dy, alpha, cache):
+    xh, s = cache
+    dxh = dy * alpha
+    dx = (dxh - dxh.mean(axis=1, keepdims=True) - xh * (dxh * xh).mean(axis=1, keepdims=True)) / s
+    return dx, dy * xh, dy        # dx, per-sample dalpha, per-sample dbeta
+
+
+# --------------------------------------------------------------------------------------------
+# LSTM family scan.  One parameterised restatement of
+#   libs/lhuclstm_layers.py:73-130,172-218      (LSTMLayer: optional proj, LN alpha-only + cell LN)
+#   libs/lasagne_libs/recurrent_layers.py:437-498   (ProjectLSTMLayer)
+#   libs/lasagne_libs/recurrent_layers.py:707-763   (LayerNormProjectLSTMLayer)
+#   libs/lasagne_libs/recurrent_layers.py:1237-1289 (InputCondLayerNormProjectLSTMLayer)
+# spec keys: N, P (0 = no projection), ln ('none'|'static'|'sample'), cell_ln, grad_clip, backwards
+# p keys: W_h (P|N,4N), b (4N)|None (added in the step after LN), W_p (N,P)|None,
+#         alpha_in, beta_in|None, alpha_hid, beta_hid|None  ((4N,) static or (B,4N) per sample),
+#         alpha_c, beta_c (N,)
+# xin (T,B,4N) is whatever the reference feeds the scan as `input_n` (x.W_x, + b or + beta where the
+# reference adds it before the scan).
+# --------------------------------------------------------------------------------------------
+def lstm_scan_fwd(xin, mask, p, spec, c0=None, h0=None):
+    T, B, _ = xin.shape
+    N = spec['N']
+    P = spec['P'] if spec['P'] else N
+    ln = spec.get('ln', 'none')
+    dt = xin.dtype
+    c = np.zeros((B, N), dt) if c0 is None else c0.astype(dt)
+    h = np.zeros((B, P), dt) if h0 is None else h0.astype(dt)
+    order = range(T - 1, -1, -1) if spec.get('backwards') else range(T)
+    hid = np.zeros((T, B, P), dt)
+    cell = np.zeros((T, B, N), dt)
+    cache = [None] * T
+    for t in order:
+        m = mask[t][:, None] != 0
+        a = h @ p['W_h']
+        ci = ch = cc = None
+        if ln != 'none':
+            gi, ci = ln_fwd(xin[t], p['alpha_in'], p.get('beta_in'))
+            gh, ch = ln_fwd(a, p['alpha_hid'], p.get('beta_hid'))
+            gates = gi + gh
+        else:
+            gates = xin[t] + a
+        if p.get('b') is not None:
+            gates = gates + p['b']
+        i = _sig(gates[:, 0 * N:1 * N])
+        f = _sig(gates[:, 1 * N:2 * N])
+        g = np.tanh(gates[:, 2 * N:3 * N])
+        o = _sig(gates[:, 3 * N:4 * N])
+        c_new = f * c + i * g
+        if spec.get('cell_ln'):
+            outcell, cc = ln_fwd(c_new, p['alpha_c'], p['beta_c'])
+        else:
+            outcell = c_new
+        tc = np.tanh(outcell)
+        r = o * tc
+        h_new = r @ p['W_p'] if p.get('W_p') is not None else r
+        cache[t] = (m, c, h, i, f, g, o, tc, r, ci, ch, cc)
+        c = np.where(m, c_new, c)
+        h = np.where(m, h_new, h)
+        hid[t] = h
+        cell[t] = c
+    return hid, cell, cache
+
+
+def lstm_scan_bwd(dhid, cache, p, spec, dcell=None):
+    """BPTT through lstm_scan_fwd.  dhid (T,B,P) = dLoss/d hid_out.  Returns dxin, grads, (dc0, dh0)."""
+    T = dhid.shape[0]
+    N = spec['N']
+    clipv = spec.get('grad_clip', 0)
+    ln = spec.get('ln', 'none')
+    dt = dhid.dtype
+    B = dhid.shape[1]
+    order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
+    g_ = {k: np.zeros_like(v) for k, v in p.items() if v is not None}
+    dh = np.zeros_like(dhid[0])
+    dc = np.zeros((B, N), dt)
+    dxin = np.zeros((T, B, 4 * N), dt)
+    for t in reversed(order):
+        (m, c_prev, h_prev, i, f, g, o, tc, r, ci, ch, cc) = cache[t]
+        dh_t = dhid[t] + dh
+        dc_t = dc + (dcell[t] if dcell is not None else 0)
+        dh_new = np.where(m, dh_t, 0)
+        dc_new = np.where(m, dc_t, 0)
+        dh_prev = np.where(m, 0, dh_t)
+        dc_prev = np.where(m, 0, dc_t)
+        if p.get('W_p') is not None:
+            g_['W_p'] += r.T @ dh_new
+            dr = dh_new @ p['W_p'].T
+        else:
+            dr = dh_new
+        do = dr * tc
+        dout = _clip(dr * o * (1 - tc * tc), clipv)
+        if spec.get('cell_ln'):
+            dcn, dal, dbe = ln_bwd(dout, p['alpha_c'], cc)
+            g_['alpha_c'] += dal.sum(0)
+            g_['beta_c'] += dbe.sum(0)
+            dc_new = dc_new + dcn
+        else:
+            dc_new = dc_new + dout
+        dgates = np.concatenate([dc_new * g * i * (1 - i), dc_new * c_prev * f * (1 - f),
+                                 dc_new * i * (1 - g * g), do * o * (1 - o)], axis=1)
+        dgates = _clip(dgates, clipv)
+        dc_prev = dc_prev + dc_new * f
+        if p.get('b') is not None:
+            g_['b'] += dgates.sum(0)
+        if ln != 'none':
+            dx_t, dal, dbe = ln_bwd(dgates, p['alpha_in'], ci)
+            g_['alpha_in'] += dal if ln == 'sample' else dal.sum(0)
+            if p.get('beta_in') is not None:
+                g_['beta_in'] += dbe if ln == 'sample' else dbe.sum(0)
+            da, dal, dbe = ln_bwd(dgates, p['alpha_hid'], ch)
+            g_['alpha_hid'] += dal if ln == 'sample' else dal.sum(0)
+            if p.get('beta_hid') is not None:
+                g_['beta_hid'] += dbe if ln == 'sample' else dbe.sum(0)
+        else:
+            dx_t = dgates
+            da = dgates
+        g_['W_h'] += h_prev.T @ da
+        dh_prev = dh_prev + da @ p['W_h'].T
+        dxin[t] = dx_t
+        dh, dc = dh_prev, dc_prev
+    return dxin, g_, (dc, dh)
+
+
+# --------------------------------------------------------------------------------------------
+# HyperLSTM scan  (libs/lasagne_libs/hyper_lhuc_layers.py:216-237 eq10, :363-412 step,
+#                  :414-425 step_masked, :427-507 get_output_for)
+# p keys: W_xhat (N+D,4H) rows [h ; x] (:218), bhat (4H), W_hhat (H,4H),
+#         W_hhat_h, W_hhat_x, W_hhat_b (H,4Z), b_hhat_h, b_hhat_x (4Z),
+#         W_hz, W_xz, W_bz (4,Z,N), b_0 (4,N), W_h (N,4N), W_x (D,4N)
+# --------------------------------------------------------------------------------------------
+def hyper_scan_fwd(x, mask, p, spec):
+    T, B, D = x.shape
+    N, H, Z = spec['N'], spec['H'], spec['Z']
+    dt = x.dtype
+    xproj = x @ p['W_x']                                  # :469
+    hc = np.zeros((B, H), dt); hh = np.zeros((B, H), dt)
+    c = np.zeros((B, N), dt); h = np.zeros((B, N), dt)
+    order = range(T - 1, -1, -1) if spec.get('backwards') else range(T)
+    hid = np.zeros((T, B, N), dt)
+    cache = [None] * T
+    for t in order:
+        m = mask[t][:, None] != 0
+        hx = np.concatenate([h, x[t]], axis=1)            # :218
+        hg = hx @ p['W_xhat'] + p['bhat'] + hh @ p['W_hhat']   # :220-221
+        hi = _sig(hg[:, 0:H]); hf = _sig(hg[:, H:2 * H])
+        hgc = np.tanh(hg[:, 2 * H:3 * H]); ho = _sig(hg[:, 3 * H:4 * H])
+        hc_new = hf * hc + hi * hgc                       # :232
+        thc = np.tanh(hc_new)
+        hh_new = ho * thc                                 # :235
+        z_h = hh_new @ p['W_hhat_h'] + p['b_hhat_h']      # :368
+        z_x = hh_new @ p['W_hhat_x'] + p['b_hhat_x']      # :369
+        z_b = hh_new @ p['W_hhat_b']                      # :370
+        d_h = np.concatenate([z_h[:, k * Z:(k + 1) * Z] @ p['W_hz'][k] for k in range(4)], axis=1)
+        d_x = np.concatenate([z_x[:, k * Z:(k + 1) * Z] @ p['W_xz'][k] for k in range(4)], axis=1)
+        bb = np.concatenate([z_b[:, k * Z:(k + 1) * Z] @ p['W_bz'][k] + p['b_0'][k]
+                             for k in range(4)], axis=1)  # :380-388
+        a = h @ p['W_h']                                  # :394
+        gates = a * d_h + (xproj[t] * d_x + bb)           # :393-395
+        i = _sig(gates[:, 0:N]); f = _sig(gates[:, N:2 * N])
+        g = np.tanh(gates[:, 2 * N:3 * N]); o = _sig(gates[:, 3 * N:4 * N])
+        c_new = f * c + i * g                             # :408
+        tc = np.tanh(c_new)
+        h_new = o * tc                                    # :411
+        cache[t] = (m, hc, hh, c, h, hx, hi, hf, hgc, ho, thc, hh_new, z_h, z_x, z_b,
+                    d_h, d_x, a, i, f, g, o, tc)
+        hc = np.where(m, hc_new, hc); hh = np.where(m, hh_new, hh)     # :419-423
+        c = np.where(m, c_new, c); h = np.where(m, h_new, h)
+        hid[t] = h
+    return hid, (cache, xproj)
+
+
+def hyper_scan_bwd(dhid, x, fwd_cache, p, spec):
+    cache, xproj = fwd_cache
+    T, B, D = x.shape
+    N, H, Z = spec['N'], spec['H'], spec['Z']
+    clipv = spec.get('grad_clip', 0)
+    dt = dhid.dtype
+    order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
+    g_ = {k: np.zeros_like(v) for k, v in p.items()}
+    dh = np.zeros((B, N), dt); dc = np.zeros((B, N), dt)
+    dhh = np.zeros((B, H), dt); dhc = np.zeros((B, H), dt)
+    dx = np.zeros((T, B, D), dt)
+    dxproj = np.zeros((T, B, 4 * N), dt)
+    for t in reversed(order):
+        (m, hc_prev, hh_prev, c_prev, h_prev, hx, hi, hf, hgc, ho, thc, hh_new, z_h, z_x, z_b,
+         d_h, d_x, a, i, f, g, o, tc) = cache[t]
+        dh_t = dhid[t] + dh
+        dh_new = np.where(m, dh_t, 0); dh_prev = np.where(m, 0, dh_t)
+        dc_new = np.where(m, dc, 0); dc_prev = np.where(m, 0, dc)
+        dhh_new = np.where(m, dhh, 0); dhh_prev = np.where(m, 0, dhh)
+        dhc_new = np.where(m, dhc, 0); dhc_prev = np.where(m, 0, dhc)
+        # main cell (:401-411)
+        do = dh_new * tc
+        dc_new = dc_new + dh_new * o * (1 - tc * tc)
+        dgates = np.concatenate([dc_new * g * i * (1 - i), dc_new * c_prev * f * (1 - f),
+                                 dc_new * i * (1 - g * g), do * o * (1 - o)], axis=1)
+        dgates = _clip(dgates, clipv)                     # :397-399 one clip on the whole vector
+        dc_prev = dc_prev + dc_new * f
+        da = dgates * d_h
+        dd_h = dgates * a
+        dxproj[t] = dgates * d_x
+        dd_x = dgates * xproj[t]
+        dbb = dgates
+        g_['W_h'] += h_prev.T @ da
+        dh_prev = dh_prev + da @ p['W_h'].T
+        dz_h = np.zeros_like(z_h); dz_x = np.zeros_like(z_x); dz_b = np.zeros_like(z_b)
+        for k in range(4):
+            sl = slice(k * Z, (k + 1) * Z); sn = slice(k * N, (k + 1) * N)
+            g_['W_hz'][k] += z_h[:, sl].T @ dd_h[:, sn]
+            g_['W_xz'][k] += z_x[:, sl].T @ dd_x[:, sn]
+            g_['W_bz'][k] += z_b[:, sl].T @ dbb[:, sn]
+            g_['b_0'][k] += dbb[:, sn].sum(0)
+            dz_h[:, sl] = dd_h[:, sn] @ p['W_hz'][k].T
+            dz_x[:, sl] = dd_x[:, sn] @ p['W_xz'][k].T
+            dz_b[:, sl] = dbb[:, sn] @ p['W_bz'][k].T
+        g_['W_hhat_h'] += hh_new.T @ dz_h; g_['b_hhat_h'] += dz_h.sum(0)
+        g_['W_hhat_x'] += hh_new.T @ dz_x; g_['b_hhat_x'] += dz_x.sum(0)
+        g_['W_hhat_b'] += hh_new.T @ dz_b
+        dhh_new = dhh_new + dz_h @ p['W_hhat_h'].T + dz_x @ p['W_hhat_x'].T + dz_b @ p['W_hhat_b'].T
+        # hyper cell (:226-235)
+        dho = dhh_new * thc
+        dhc_new = dhc_new + dhh_new * ho * (1 - thc * thc)
+        dhg = np.concatenate([dhc_new * hgc * hi * (1 - hi), dhc_new * hc_prev * hf * (1 - hf),
+                              dhc_new * hi * (1 - hgc * hgc), dho * ho * (1 - ho)], axis=1)
+        dhg = _clip(dhg, clipv)                           # :222-224
+        dhc_prev = dhc_prev + dhc_new * hf
+        g_['W_xhat'] += hx.T @ dhg
+        g_['bhat'] += dhg.sum(0)
+        g_['W_hhat'] += hh_prev.T @ dhg
+        dhx = dhg @ p['W_xhat'].T
+        dh_prev = dh_prev + dhx[:, :N]
+        dx[t] = dhx[:, N:]
+        dhh_prev = dhh_prev + dhg @ p['W_hhat'].T
+        dh, dc, dhh, dhc = dh_prev, dc_prev, dhh_prev, dhc_prev
+    g_['W_x'] += x.reshape(T * B, D).T @ dxproj.reshape(T * B, 4 * N)
+    dx += dxproj @ p['W_x'].T
+    return dx, g_
+
+
+# --------------------------------------------------------------------------------------------
+# Layer wrappers.  Each takes x (B,T,D) batch-major like the reference layers, a parameter dict
+# keyed by the reference's add_param names, and returns (B,T,out) plus a cache for backward.
+# --------------------------------------------------------------------------------------------
+GATES_LHUC = ('ig', 'fg', 'c', 'og')                       # libs/lhuclstm_layers.py:53-56
+GATES_REC = ('ingate', 'forgetgate', 'cell', 'outgate')    # recurrent_layers.py:341-359
+
+
+def _tm(x):       # dimshuffle(1,0,2)
+    return np.ascontiguousarray(np.swapaxes(x, 0, 1))
+
+
+def _stack(P, fmt, gates, axis=1):
+    return np.concatenate([P[fmt.format(g)] for g in gates], axis=axis)
+
+
+def _unstack_into(G, fmt, gates, val, axis=1):
+    n = val.shape[axis] // 4
+    for k, g in enumerate(gates):
+        idx = [slice(None)] * val.ndim
+        idx[axis] = slice(k * n, (k + 1) * n)
+        G[fmt.format(g)] = val[tuple(idx)]
+
+
+class OracleLayer(object):
+    """Base: forward(x, mask, cond) -> y ; backward(dy) -> dx, fills self.grads (name -> array)."""
+    def forward(self, x, mask, cond=None):
+        raise NotImplementedError
+
+    def backward(self, dy):
+        raise NotImplementedError
+
+
+class LSTMLayerO(OracleLayer):
+    """libs/lhuclstm_layers.py:141-218 (LSTMLayer) and :220-324 (TBPTTLSTMLayer when stateful)."""
+    def __init__(self, P, num_units, num_proj_units=0, use_layer_norm=False, grad_clipping=0,
+                 backwards=False, stateful=False, context=0):
+        self.P = P; self.N = num_units; self.Pj = num_proj_units; self.ln = use_layer_norm
+        self.spec = dict(N=num_units, P=num_proj_units, ln='static' if use_layer_norm else 'none',
+                         cell_ln=use_layer_norm, grad_clip=grad_clipping, backwards=backwards)
+        self.stateful = stateful; self.context = context
+        self.c0 = None; self.h0 = None
+
+    def reset(self, batch_size):                        # :221-228
+        self.c0 = np.zeros((batch_size, self.N)); self.h0 = np.zeros((batch_size, self.Pj or self.N))
+
+    def _p(self):
+        P = self.P
+        p = dict(W_h=_stack(P, 'W_h_{}', GATES_LHUC), b=_stack(P, 'b_{}', GATES_LHUC, axis=0),
+                 W_p=P.get('W_p'))
+        if self.ln:                                     # :77-78 alpha only, :101 cell LN alpha+beta
+            p.update(alpha_in=P['W_x_alpha'], alpha_hid=P['W_h_alpha'], alpha_c=P['W_c_alpha'],
+                     beta_c=P['W_c_beta'])
+        return p
+
+    def forward(self, x, mask, cond=None):
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        self.Wx = _stack(self.P, 'W_x_{}', GATES_LHUC)
+        xin = self.x @ self.Wx                          # :189
+        self.p = self._p()
+        c0 = self.c0 if self.stateful else None
+        h0 = self.h0 if self.stateful else None
+        hid, cell, self.cache = lstm_scan_fwd(xin, m, self.p, self.spec, c0, h0)
+        if self.stateful:                               # :313-319
+            T = hid.shape[0]
+            last = -1
+            if self.context:
+                last = (T if T < self.context else self.context) - 1
+            self.c0 = cell[last].copy(); self.h0 = hid[last].copy()
+        return _tm(hid)
+
+    def backward(self, dy):
+        dxin, g, _ = lstm_scan_bwd(_tm(dy), self.cache, self.p, self.spec)
+        T, B, D = self.x.shape
+        G = {}
+        _unstack_into(G, 'W_h_{}', GATES_LHUC, g['W_h'])
+        _unstack_into(G, 'b_{}', GATES_LHUC, g['b'], axis=0)
+        _unstack_into(G, 'W_x_{}', GATES_LHUC, self.x.reshape(T * B, D).T @ dxin.reshape(T * B, -1))
+        if self.Pj:
+            G['W_p'] = g['W_p']
+        if self.ln:
+            G.update(W_x_alpha=g['alpha_in'], W_h_alpha=g['alpha_hid'], W_c_alpha=g['alpha_c'],
+                     W_c_beta=g['beta_c'])
+        self.grads = G
+        return _tm(dxin @ self.Wx.T)
+
+
+class LHUCLSTMLayerO(LSTMLayerO):
+    """libs/lhuclstm_layers.py:326-471 SpeakerLHUCLSTMLayer with the i-vector embedding (:491-510):
+    A1 recurrence, then hid_out *= relu(MLP(embedding)) after the scan (:461-462)."""
+    def __init__(self, P, num_units, num_pred_units, num_pred_layers, **kw):
+        LSTMLayerO.__init__(self, P, num_units, **kw)
+        self.npl = num_pred_layers
+
+    def forward(self, x, mask, cond=None):
+        hid = LSTMLayerO.forward(self, x, mask)
+        emb = cond[:, 0, :]                             # :504-510 first frame of the i-vector
+        acts = [emb]
+        for i in range(self.npl):                       # :405-407
+            acts.append(np.maximum(acts[-1] @ self.P['W_e_h_%d' % i] + self.P['b_e_h_%d' % i], 0))
+        sf = acts[-1] @ self.P['W_e_h_%d' % self.npl] + self.P['b_e_h_%d' % self.npl]   # :409
+        self.acts = acts; self.sf = sf; self.hid = hid
+        return hid * np.maximum(sf, 0)[:, None, :]      # :462
+
+    def backward(self, dy):
+        dsf = (dy * self.hid).sum(1) * (self.sf > 0)
+        dhid = dy * np.maximum(self.sf, 0)[:, None, :]
+        dx = LSTMLayerO.backward(self, dhid)
+        G = self.grads
+        G['W_e_h_%d' % self.npl] = self.acts[-1].T @ dsf
+        G['b_e_h_%d' % self.npl] = dsf.sum(0)
+        da = dsf @ self.P['W_e_h_%d' % self.npl].T
+        for i in range(self.npl - 1, -1, -1):
+            da = da * (self.acts[i + 1] > 0)
+            G['W_e_h_%d' % i] = self.acts[i].T @ da
+            G['b_e_h_%d' % i] = da.sum(0)
+            da = da @ self.P['W_e_h_%d' % i].T
+        return dx
+
+
+class ProjectLSTMLayerO(OracleLayer):
+    """libs/lasagne_libs/recurrent_layers.py:290-546 (no peepholes, learn_init False)."""
+    ln = 'none'
+
+    def __init__(self, P, num_units, num_factors=None, grad_clipping=0, backwards=False):
+        self.P = P; self.N = num_units; self.F = num_factors or num_units // 2
+        self.spec = dict(N=num_units, P=self.F, ln=self.ln, cell_ln=(self.ln == 'static'),
+                         grad_clip=grad_clipping, backwards=backwards)
+
+    def _p(self):
+        return dict(W_h=_stack(self.P, 'W_hid_to_{}', GATES_REC), W_p=self.P['W_hid_prj'],
+                    b=_stack(self.P, 'b_{}', GATES_REC, axis=0))
+
+    def forward(self, x, mask, cond=None):
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        self.Wx = _stack(self.P, 'W_in_to_{}', GATES_REC)
+        xin = self.x @ self.Wx                          # :431 (+b_stacked: same sum, added in step)
+        self.p = self._p()
+        hid, _, self.cache = lstm_scan_fwd(xin, m, self.p, self.spec)
+        return _tm(hid)
+
+    def backward(self, dy):
+        dxin, g, _ = lstm_scan_bwd(_tm(dy), self.cache, self.p, self.spec)
+        T, B, D = self.x.shape
+        G = {'W_hid_prj': g['W_p']}
+        _unstack_into(G, 'W_hid_to_{}', GATES_REC, g['W_h'])
+        _unstack_into(G, 'b_{}', GATES_REC, g['b'], axis=0)
+        _unstack_into(G, 'W_in_to_{}', GATES_REC, self.x.reshape(T * B, D).T @ dxin.reshape(T * B, -1))
+        self._extra_grads(G, g)
+        self.grads = G
+        return _tm(dxin @ self.Wx.T)
+
+    def _extra_grads(self, G, g):
+        pass
+
+
+class LayerNormProjectLSTMLayerO(ProjectLSTMLayerO):
+    """libs/lasagne_libs/recurrent_layers.py:548-814: ln(x_t;a,b)+ln(hW;a,b)+b_stacked, cell LN."""
+    ln = 'static'
+
+    def _p(self):
+        p = ProjectLSTMLayerO._p(self)
+        P = self.P
+        p.update(alpha_in=P['W_alpha_in'], beta_in=P['W_beta_in'], alpha_hid=P['W_alpha_hid'],
+                 beta_hid=P['W_beta_hid'], alpha_c=P['W_alpha_cell'], beta_c=P['W_beta_cell'])
+        return p
+
+    def _extra_grads(self, G, g):
+        G.update(W_alpha_in=g['alpha_in'], W_beta_in=g['beta_in'], W_alpha_hid=g['alpha_hid'],
+                 W_beta_hid=g['beta_hid'], W_alpha_cell=g['alpha_c'], W_beta_cell=g['beta_c'])
+
+
+class InputCondLayerNormProjectLSTMLayerO(OracleLayer):
+    """libs/lasagne_libs/recurrent_layers.py:1075-1338: per-sample alpha/beta from the i-vector."""
+    def __init__(self, P, num_units, num_factors, grad_clipping=0, backwards=False):
+        self.P = P; self.N = num_units; self.F = num_factors
+        self.spec = dict(N=num_units, P=num_units // 2, ln='sample', cell_ln=False,
+                         grad_clip=grad_clipping, backwards=backwards)
+
+    def forward(self, x, mask, cond=None):
+        P = self.P
+        pre = np.tanh(cond @ P['W_cond_prj'] + P['b_cond_prj'])         # :1209-1210
+        msum = mask.sum(axis=1, keepdims=True)
+        s = (pre * mask[:, :, None]).sum(axis=1) / msum                 # :1211
+        self.cond = cond; self.pre = pre; self.maskbt = mask; self.msum = msum; self.s = s
+        alpha_in = s @ P['W_alpha_in'] + P['b_alpha_in']                # :1215
+        alpha_hid = s @ P['W_alpha_hid'] + P['b_alpha_hid']             # :1216
+        beta = s @ P['W_beta'] + P['b_beta']                            # :1217
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        self.Wx = _stack(P, 'W_in_to_{}', GATES_REC)
+        xin = self.x @ self.Wx + beta[None]                             # :1233
+        self.p = dict(W_h=_stack(P, 'W_hid_to_{}', GATES_REC), W_p=P['W_hid_prj'], b=None,
+                      alpha_in=alpha_in, alpha_hid=alpha_hid)
+        hid, _, self.cache = lstm_scan_fwd(xin, m, self.p, self.spec)
+        return _tm(hid)
+
+    def get_sample_feat(self):                                          # :1337-1338
+        return self.s
+
+    def backward(self, dy):
+        P = self.P
+        dxin, g, _ = lstm_scan_bwd(_tm(dy), self.cache, self.p, self.spec)
+        T, B, D = self.x.shape
+        G = {'W_hid_prj': g['W_p']}
+        _unstack_into(G, 'W_hid_to_{}', GATES_REC, g['W_h'])
+        _unstack_into(G, 'W_in_to_{}', GATES_REC, self.x.reshape(T * B, D).T @ dxin.reshape(T * B, -1))
+        dbeta = dxin.sum(0)                                             # (B,4N)
+        dal_in, dal_hid = g['alpha_in'], g['alpha_hid']
+        s = self.s
+        G['W_alpha_in'] = s.T @ dal_in; G['b_alpha_in'] = dal_in.sum(0)
+        G['W_alpha_hid'] = s.T @ dal_hid; G['b_alpha_hid'] = dal_hid.sum(0)
+        G['W_beta'] = s.T @ dbeta; G['b_beta'] = dbeta.sum(0)
+        ds = dal_in @ P['W_alpha_in'].T + dal_hid @ P['W_alpha_hid'].T + dbeta @ P['W_beta'].T
+        dpre = (ds / self.msum)[:, None, :] * self.maskbt[:, :, None] * (1 - self.pre ** 2)
+        Bc, Tc, I = self.cond.shape
+        G['W_cond_prj'] = self.cond.reshape(Bc * Tc, I).T @ dpre.reshape(Bc * Tc, -1)
+        G['b_cond_prj'] = dpre.sum((0, 1))
+        self.grads = G
+        return _tm(dxin @ self.Wx.T)
+
+
+class HyperLSTMLayerO(OracleLayer):
+    """libs/lasagne_libs/hyper_lhuc_layers.py:168-507."""
+    def __init__(self, P, num_units, num_hyper_units, num_proj_units, grad_clipping=0, backwards=False):
+        self.P = P
+        self.spec = dict(N=num_units, H=num_hyper_units, Z=num_proj_units, grad_clip=grad_clipping,
+                         backwards=backwards)
+
+    def forward(self, x, mask, cond=None):
+        P = self.P; G4 = GATES_LHUC
+        self.p = dict(
+            W_xhat=_stack(P, 'W_xhat_{}', G4), bhat=_stack(P, 'bhat_{}', G4, 0),
+            W_hhat=_stack(P, 'W_hhat_{}', G4),
+            W_hhat_h=_stack(P, 'W_hhat_h_{}', G4), b_hhat_h=_stack(P, 'b_hhat_h_{}', G4, 0),
+            W_hhat_x=_stack(P, 'W_hhat_x_{}', G4), b_hhat_x=_stack(P, 'b_hhat_x_{}', G4, 0),
+            W_hhat_b=_stack(P, 'W_hhat_b_{}', G4),
+            W_hz=np.stack([P['W_hz_' + g] for g in G4]), W_xz=np.stack([P['W_xz_' + g] for g in G4]),
+            W_bz=np.stack([P['W_bz_' + g] for g in G4]), b_0=np.stack([P['b_0_' + g] for g in G4]),
+            W_h=_stack(P, 'W_h_{}', G4), W_x=_stack(P, 'W_x_{}', G4))
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        hid, self.cache = hyper_scan_fwd(self.x, m, self.p, self.spec)
+        return _tm(hid)
+
+    def backward(self, dy):
+        dx, g = hyper_scan_bwd(_tm(dy), self.x, self.cache, self.p, self.spec)
+        G = {}; G4 = GATES_LHUC
+        for nm in ('W_xhat', 'W_hhat', 'W_hhat_h', 'W_hhat_x', 'W_hhat_b', 'W_h', 'W_x'):
+            _unstack_into(G, nm + '_{}', G4, g[nm])
+        for nm in ('bhat', 'b_hhat_h', 'b_hhat_x'):
+            _unstack_into(G, nm + '_{}', G4, g[nm], axis=0)
+        for k, gn in enumerate(G4):
+            for nm in ('W_hz', 'W_xz', 'W_bz', 'b_0'):
+                G[nm + '_' + gn] = g[nm][k]
+        self.grads = G
+        return _tm(dx)
+
+
+# --------------------------------------------------------------------------------------------
+# Output layer + loss
+# --------------------------------------------------------------------------------------------
+def log_softmax(a):
+    a = a - a.max(axis=-1, keepdims=True)                  # bin/forward_ln_lstmp.py:57-58
+    return a - np.log(np.exp(a).sum(axis=-1, keepdims=True))
+
+
+def softmax_ce(logits, target, target_mask):
+    """libs/comp_graph_utils.py:29-45 (probabilities -> categorical_crossentropy) and
+    scripts/hypernets/exp_prj_ln_lstm_fix.py:84-95 (logits -> log-softmax -> one-hot CE): the same
+    number.  Returns ce_cost (= sum/n_batch, the differentiated scalar), ce_frame_sum, pred_idx,
+    dlogits."""
+    B, T, C = logits.shape
+    lp = log_softmax(logits)
+    ce = -np.take_along_axis(lp, target[:, :, None].astype(np.int64), axis=2)[:, :, 0] * target_mask
+    ce_frame_sum = ce.sum()
+    pred_idx = logits.argmax(axis=-1)
+    dl = np.exp(lp)
+    np.put_along_axis(dl, target[:, :, None].astype(np.int64),
+                      np.take_along_axis(dl, target[:, :, None].astype(np.int64), 2) - 1.0, axis=2)
+    dl = dl * (target_mask[:, :, None] / B)
+    return ce_frame_sum / B, ce_frame_sum, pred_idx, dl
+
+
+def adam_step(params, grads, m, v, t_prev, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+    """libs/lasagne_libs/updates.py:587-617.  In-place on lists of arrays; returns t."""
+    t = t_prev + 1
+    a_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    for p_, g_, m_, v_ in zip(params, grads, m, v):
+        m_[...] = b1 * m_ + (1 - b1) * g_
+        v_[...] = b2 * v_ + (1 - b2) * g_ ** 2
+        p_[...] = p_ - a_t * m_ / (np.sqrt(v_) + eps)
+    return t
+
+
+def gen_win(batch, win_size, right_context=0):
+    """libs/utils.py:178-191."""
+    n_seq = batch[0].shape[1]
+    for i in range(0, n_seq, win_size):
+        yield tuple(a[:, i:i + win_size + right_context] for a in batch)
+
+
+# --------------------------------------------------------------------------------------------
+# Network = the wiring of libs/deep_lstm_builder.py:9-88, libs/deep_hyperlstm_builder.py:8-37,
+# libs/deep_lhuclstm_builder.py:49-83,118-143, models/gating_hyper_nets.py:256-307,384-462,
+# driven by the plain-data description the product's Network.describe() emits:
+#   {'layers': [ {'fwd': {...}, 'bwd': {...}|None}, ... ], 'output': 'softmax'|'logits',
+#    'ivector_concat': bool, 'cond': bool}
+# each direction dict: {'kind', 'args': {...}, 'params': [names in add_param order]}
+# --------------------------------------------------------------------------------------------
+_KINDS = dict(lstm=LSTMLayerO, lhuc=LHUCLSTMLayerO, prj=ProjectLSTMLayerO,
+              ln_prj=LayerNormProjectLSTMLayerO, icond_ln_prj=InputCondLayerNormProjectLSTMLayerO,
+              hyper=HyperLSTMLayerO)
+
+
+class OracleNetwork(object):
+    def __init__(self, desc, values, dtype=np.float64):
+        self.desc = desc
+        vals = [np.asarray(v, dtype=dtype) for v in values]
+        self.dtype = dtype
+        self.names = []
+        self.layers = []
+        k = 0
+        for L in desc['layers']:
+            pair = []
+            for d in ('fwd', 'bwd'):
+                spec = L.get(d)
+                if spec is None:
+                    pair.append(None); continue
+                P = {}
+                for nm in spec['params']:
+                    P[nm] = vals[k]; k += 1
+                lay = _KINDS[spec['kind']](P, **spec['args'])
+                lay.param_names = list(spec['params'])
+                pair.append(lay)
+            self.layers.append(pair)
+        self.W = vals[k]; self.b = vals[k + 1]; k += 2
+        assert k == len(vals), (k, len(vals))
+        self.values = vals
+
+    def tbptt_layers(self):
+        return [p[0] for p in self.layers if getattr(p[0], 'stateful', False)]
+
+    def forward(self, x, mask, cond=None):
+        x = np.asarray(x, self.dtype); mask = np.asarray(mask, self.dtype)
+        if cond is not None:
+            cond = np.asarray(cond, self.dtype)
+        if self.desc.get('ivector_concat'):
+            x = np.concatenate([x, cond], axis=-1)          # libs/deep_lstm_builder.py:14-16
+        self.acts = [x]
+        self.split = []
+        for f, b in self.layers:
+            yf = f.forward(self.acts[-1], mask, cond)
+            self.split.append(yf.shape[-1])
+            y = yf if b is None else np.concatenate([yf, b.forward(self.acts[-1], mask, cond)], -1)
+            self.acts.append(y)
+        self.logits = self.acts[-1] @ self.W + self.b      # libs/builder_utils.py:44-45
+        return self.logits
+
+    def posteriors(self, x, mask, cond=None):
+        """What ff_fn returns: probabilities for build_* nets (libs/comp_graph_utils.py:321-333),
+        logits for gating_hyper_nets models (models/gating_hyper_nets.py:304-306)."""
+        lg = self.forward(x, mask, cond)
+        return np.exp(log_softmax(lg)) if self.desc['output'] == 'softmax' else lg
+
+    def loss_and_grads(self, x, mask, target, target_mask, cond=None, context=0):
+        lg = self.forward(x, mask, cond)
+        tm = np.asarray(target_mask, self.dtype)
+        if context:                                        # libs/comp_graph_utils.py:26-27,54-55
+            tm = tm.copy(); tm[:, context:] = 0
+        ce_cost, ce_sum, pred, dl = softmax_ce(lg, np.asarray(target), tm)
+        B, T, C = lg.shape
+        top = self.acts[-1]
+        gW = top.reshape(B * T, -1).T @ dl.reshape(B * T, C)
+        gb = dl.sum((0, 1))
+        dy = dl @ self.W.T
+        grads_rev = []
+        for (f, b), nf in zip(reversed(self.layers), reversed(self.split)):
+            if b is None:
+                dx = f.backward(dy)
+                grads_rev.append([f.grads[n] for n in f.param_names])
+            else:
+                dxf = f.backward(dy[..., :nf]); dxb = b.backward(dy[..., nf:])
+                dx = dxf + dxb
+                grads_rev.append([f.grads[n] for n in f.param_names] +
+                                 [b.grads[n] for n in b.param_names])
+            dy = dx
+        grads = [g for lg_ in reversed(grads_rev) for g in lg_] + [gW, gb]
+        if context:
+            pred = pred[:, :context]
+        return ce_cost, ce_sum, pred, grads

@@ -1,0 +1,185 @@
+"""Second, independent restatement of the reference layers used ONLY to pin the numpy oracle:
+torch float64, written step by step after the reference `get_output_for` bodies and differentiated
+by torch autograd (the oracle's backward is hand-derived).  grad_clip is a custom autograd Function
+with Theano's semantics (identity forward, clip of the incoming gradient backward)."""
+import torch
+
+EPS = float(torch.finfo(torch.float32).eps)
+
+
+class _GradClip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.c = c
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clamp(-ctx.c, ctx.c), None
+
+
+def grad_clip(x, c):
+    return _GradClip.apply(x, c) if c else x
+
+
+def ln(x, alpha, beta=None):                       # libs/lhuclstm_layers.py:16-21
+    out = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, keepdim=True, unbiased=False) + EPS)
+    out = out * alpha
+    if beta is not None:
+        out = out + beta
+    return out
+
+
+def _cat(P, fmt, gates, dim=1):
+    return torch.cat([P[fmt.format(g)] for g in gates], dim=dim)
+
+
+G_L = ('ig', 'fg', 'c', 'og')
+G_R = ('ingate', 'forgetgate', 'cell', 'outgate')
+
+
+def _scan(step, seqs, init, backwards):
+    T = seqs[0].shape[0]
+    order = range(T - 1, -1, -1) if backwards else range(T)
+    state = init
+    outs = []
+    for t in order:
+        state = step(*[s[t] for s in seqs], *state)
+        outs.append(state)
+    return [torch.stack([o[k] for o in outs]) for k in range(len(init))]
+
+
+def lstm_layer(P, x, mask, N, Pj=0, use_ln=False, clip=0, backwards=False, c0=None, h0=None,
+               return_cell=False):
+    """libs/lhuclstm_layers.py:73-130,172-218."""
+    W_h = _cat(P, 'W_h_{}', G_L); W_x = _cat(P, 'W_x_{}', G_L); b = _cat(P, 'b_{}', G_L, 0)
+    inp = x.transpose(0, 1)
+    B = inp.shape[1]
+    cell_init = torch.zeros(B, N, dtype=x.dtype) if c0 is None else c0
+    hid_init = torch.zeros(B, Pj or N, dtype=x.dtype) if h0 is None else h0
+    inp = inp @ W_x
+    m = mask.transpose(0, 1).unsqueeze(-1)
+
+    def step(input_n, mask_n, cell_previous, hid_previous):
+        if use_ln:
+            gates = ln(input_n, P['W_x_alpha'])
+            gates = gates + ln(hid_previous @ W_h, P['W_h_alpha'])
+        else:
+            gates = input_n + hid_previous @ W_h
+        gates = gates + b
+        ig, fg, ci, og = [grad_clip(gates[:, k * N:(k + 1) * N], clip) for k in range(4)]
+        ig = torch.sigmoid(ig); fg = torch.sigmoid(fg); ci = torch.tanh(ci); og = torch.sigmoid(og)
+        cell = fg * cell_previous + ig * ci
+        outcell = ln(cell, P['W_c_alpha'], P['W_c_beta']) if use_ln else cell
+        outcell = grad_clip(outcell, clip)
+        hid = og * torch.tanh(outcell)
+        if Pj:
+            hid = hid @ P['W_p']
+        cell = torch.where(mask_n != 0, cell, cell_previous)
+        hid = torch.where(mask_n != 0, hid, hid_previous)
+        return [cell, hid]
+
+    cell_out, hid_out = _scan(step, [inp, m], [cell_init, hid_init], backwards)
+    hid_out = hid_out.transpose(0, 1); cell_out = cell_out.transpose(0, 1)
+    if return_cell:
+        return hid_out, cell_out            # iteration order (used for TBPTT state, forward only)
+    if backwards:
+        hid_out = hid_out.flip(1)
+    return hid_out
+
+
+def lhuc_layer(P, x, mask, ivec, N, npl, **kw):
+    """libs/lhuclstm_layers.py:402-468,504-510."""
+    hid = lstm_layer(P, x, mask, N, **kw)
+    pred = ivec.transpose(0, 1)[0]
+    for i in range(npl):
+        pred = torch.relu(pred @ P['W_e_h_%d' % i] + P['b_e_h_%d' % i])
+    sf = pred @ P['W_e_h_%d' % npl] + P['b_e_h_%d' % npl]
+    return hid * torch.relu(sf).unsqueeze(1)
+
+
+def prj_layer(P, x, mask, N, clip=0, backwards=False, kind='prj', cond=None):
+    """recurrent_layers.py:404-546 (prj), :674-814 (ln_prj), :1202-1335 (icond_ln_prj)."""
+    W_in = _cat(P, 'W_in_to_{}', G_R); W_hid = _cat(P, 'W_hid_to_{}', G_R)
+    F = W_hid.shape[0]
+    inp = x.transpose(0, 1)
+    m = mask.transpose(0, 1).unsqueeze(-1)
+    B = inp.shape[1]
+    if kind == 'icond_ln_prj':
+        li = torch.tanh(cond @ P['W_cond_prj'] + P['b_cond_prj'])
+        li = (li * mask.unsqueeze(-1)).sum(1) / mask.sum(1, keepdim=True)
+        alpha_in = li @ P['W_alpha_in'] + P['b_alpha_in']
+        alpha_hid = li @ P['W_alpha_hid'] + P['b_alpha_hid']
+        beta = li @ P['W_beta'] + P['b_beta']
+        inp = inp @ W_in + beta
+    elif kind == 'prj':
+        inp = inp @ W_in + _cat(P, 'b_{}', G_R, 0)
+    else:
+        inp = inp @ W_in
+        b_stacked = _cat(P, 'b_{}', G_R, 0)
+
+    def step(input_n, mask_n, cell_previous, hid_previous):
+        if kind == 'prj':
+            gates = input_n + hid_previous @ W_hid
+        elif kind == 'ln_prj':
+            gates = ln(input_n, P['W_alpha_in'], P['W_beta_in'])
+            gates = gates + ln(hid_previous @ W_hid, P['W_alpha_hid'], P['W_beta_hid'])
+            gates = gates + b_stacked
+        else:
+            gates = ln(input_n, alpha_in) + ln(hid_previous @ W_hid, alpha_hid)
+        ig, fg, ci, og = [grad_clip(gates[:, k * N:(k + 1) * N], clip) for k in range(4)]
+        ig = torch.sigmoid(ig); fg = torch.sigmoid(fg); ci = torch.tanh(ci); og = torch.sigmoid(og)
+        cell = fg * cell_previous + ig * ci
+        outcell = ln(cell, P['W_alpha_cell'], P['W_beta_cell']) if kind == 'ln_prj' else cell
+        outcell = grad_clip(outcell, clip)
+        hid = (og * torch.tanh(outcell)) @ P['W_hid_prj']
+        cell = torch.where(mask_n != 0, cell, cell_previous)
+        hid = torch.where(mask_n != 0, hid, hid_previous)
+        return [cell, hid]
+
+    init = [torch.zeros(B, N, dtype=x.dtype), torch.zeros(B, F, dtype=x.dtype)]
+    _, hid_out = _scan(step, [inp, m], init, backwards)
+    hid_out = hid_out.transpose(0, 1)
+    return hid_out.flip(1) if backwards else hid_out
+
+
+def hyper_layer(P, x, mask, N, H, Z, clip=0, backwards=False):
+    """libs/lasagne_libs/hyper_lhuc_layers.py:216-237,363-507."""
+    W_h = _cat(P, 'W_h_{}', G_L); W_x = _cat(P, 'W_x_{}', G_L)
+    W_hhat = _cat(P, 'W_hhat_{}', G_L); W_xhat = _cat(P, 'W_xhat_{}', G_L); bhat = _cat(P, 'bhat_{}', G_L, 0)
+    W_hhat_h = _cat(P, 'W_hhat_h_{}', G_L); W_hhat_x = _cat(P, 'W_hhat_x_{}', G_L)
+    W_hhat_b = _cat(P, 'W_hhat_b_{}', G_L)
+    b_hhat_h = _cat(P, 'b_hhat_h_{}', G_L, 0); b_hhat_x = _cat(P, 'b_hhat_x_{}', G_L, 0)
+    orig = x.transpose(0, 1)
+    inp = orig @ W_x
+    m = mask.transpose(0, 1).unsqueeze(-1)
+    B = orig.shape[1]
+
+    def step(orig_input_n, input_n, mask_n, hc_prev, hh_prev, c_prev, h_prev):
+        hin = torch.cat([h_prev, orig_input_n], 1) @ W_xhat + bhat
+        hg = grad_clip(hin + hh_prev @ W_hhat, clip)
+        hig = torch.sigmoid(hg[:, 0:H]); hfg = torch.sigmoid(hg[:, H:2 * H])
+        hci = torch.tanh(hg[:, 2 * H:3 * H])
+        hc = hfg * hc_prev + hig * hci
+        hog = torch.sigmoid(hg[:, 3 * H:4 * H])
+        hh = hog * torch.tanh(hc)
+        z_h = hh @ W_hhat_h + b_hhat_h; z_x = hh @ W_hhat_x + b_hhat_x; z_b = hh @ W_hhat_b
+        d_h = torch.cat([z_h[:, k * Z:(k + 1) * Z] @ P['W_hz_' + g] for k, g in enumerate(G_L)], 1)
+        d_x = torch.cat([z_x[:, k * Z:(k + 1) * Z] @ P['W_xz_' + g] for k, g in enumerate(G_L)], 1)
+        bb = torch.cat([z_b[:, k * Z:(k + 1) * Z] @ P['W_bz_' + g] + P['b_0_' + g]
+                        for k, g in enumerate(G_L)], 1)
+        inn = input_n * d_x + bb
+        gates = grad_clip((h_prev @ W_h) * d_h + inn, clip)
+        ig = torch.sigmoid(gates[:, 0:N]); fg = torch.sigmoid(gates[:, N:2 * N])
+        ci = torch.tanh(gates[:, 2 * N:3 * N])
+        cell = fg * c_prev + ig * ci
+        og = torch.sigmoid(gates[:, 3 * N:4 * N])
+        hid = og * torch.tanh(cell)
+        k = mask_n != 0
+        return [torch.where(k, hc, hc_prev), torch.where(k, hh, hh_prev),
+                torch.where(k, cell, c_prev), torch.where(k, hid, h_prev)]
+
+    z = lambda n: torch.zeros(B, n, dtype=x.dtype)
+    outs = _scan(step, [orig, inp, m], [z(H), z(H), z(N), z(N)], backwards)
+    hid_out = outs[3].transpose(0, 1)
+    return hid_out.flip(1) if backwards else hid_out

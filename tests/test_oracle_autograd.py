@@ -1,0 +1,137 @@
+"""Pins the numpy oracle (hand-derived BPTT) against an independent torch float64 transliteration
+of the reference step functions differentiated by autograd, for every layer kind on the hot path,
+both scan directions, grad_clipping in {0, active}.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import ref_torch as R
+from common import make_params, make_batch
+from asr_amd import specs
+from oracle import asr_oracle as O
+
+B, T, D, N, PJ, H, Z, F, I, C = 3, 7, 5, 8, 4, 4, 2, 3, 3, 6
+
+
+def _t(P):
+    return {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in P.items()}
+
+
+def _check(layer_o, torch_fn, P, x, mask, cond=None, tol=1e-9):
+    rng = np.random.default_rng(7)
+    y = layer_o.forward(x.astype(np.float64), mask.astype(np.float64),
+                        None if cond is None else cond.astype(np.float64))
+    w = rng.standard_normal(y.shape) * 3.0          # large enough that grad_clip bites
+    dx = layer_o.backward(w)
+    Pt = _t(P)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    mt = torch.tensor(mask, dtype=torch.float64)
+    ct = None if cond is None else torch.tensor(cond, dtype=torch.float64)
+    yt = torch_fn(Pt, xt, mt, ct)
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=tol, atol=tol)
+    (yt * torch.tensor(w)).sum().backward()
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-8, atol=1e-9)
+    for k in P:
+        g = Pt[k].grad
+        assert g is not None, k
+        np.testing.assert_allclose(layer_o.grads[k], g.numpy(), rtol=1e-8, atol=1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip', [0, 0.3])
+@pytest.mark.parametrize('pj,use_ln', [(0, False), (PJ, False), (0, True), (PJ, True)])
+def test_lstm_layer(backwards, clip, pj, use_ln):
+    rng = np.random.default_rng(11)
+    P = make_params(rng, specs.lstm_params(D, N, pj, use_ln), perturb=0.2, scale=1.5)
+    b = make_batch(rng, B, T, D, C)
+    lay = O.LSTMLayerO(P, N, num_proj_units=pj, use_layer_norm=use_ln, grad_clipping=clip,
+                       backwards=backwards)
+    _check(lay, lambda Pt, x, m, c: R.lstm_layer(Pt, x, m, N, pj, use_ln, clip, backwards),
+           P, b['x'], b['mask'])
+
+
+@pytest.mark.parametrize('backwards', [False, True])
+def test_lhuc_layer(backwards):
+    rng = np.random.default_rng(12)
+    P = make_params(rng, specs.lhuc_params(D, N, 0, False, I, 5, 1), perturb=0.3)
+    b = make_batch(rng, B, T, D, C, I=I)
+    lay = O.LHUCLSTMLayerO(P, N, 5, 1, grad_clipping=0.5, backwards=backwards)
+    _check(lay, lambda Pt, x, m, c: R.lhuc_layer(Pt, x, m, c, N, 1, clip=0.5, backwards=backwards),
+           P, b['x'], b['mask'], b['ivec'])
+
+
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip', [0, 0.3])
+@pytest.mark.parametrize('kind', ['prj', 'ln_prj', 'icond_ln_prj'])
+def test_prj_family(backwards, clip, kind):
+    rng = np.random.default_rng(13)
+    if kind == 'prj':
+        P = make_params(rng, specs.prj_params(D, N, PJ), perturb=0.2, scale=1.5)
+        lay = O.ProjectLSTMLayerO(P, N, PJ, clip, backwards)
+    elif kind == 'ln_prj':
+        P = make_params(rng, specs.ln_prj_params(D, N, PJ), perturb=0.2, scale=1.5)
+        lay = O.LayerNormProjectLSTMLayerO(P, N, PJ, clip, backwards)
+    else:
+        P = make_params(rng, specs.icond_ln_prj_params(D, N, F, I), perturb=0.2, scale=1.5)
+        lay = O.InputCondLayerNormProjectLSTMLayerO(P, N, F, clip, backwards)
+    b = make_batch(rng, B, T, D, C, I=I)
+    cond = b['ivec'] if kind == 'icond_ln_prj' else None
+    _check(lay, lambda Pt, x, m, c: R.prj_layer(Pt, x, m, N, clip, backwards, kind, c),
+           P, b['x'], b['mask'], cond)
+
+
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip', [0, 0.3])
+def test_hyper_layer(backwards, clip):
+    rng = np.random.default_rng(14)
+    P = make_params(rng, specs.hyper_params(D, N, H, Z), perturb=0.3, scale=1.5)
+    b = make_batch(rng, B, T, D, C)
+    lay = O.HyperLSTMLayerO(P, N, H, Z, clip, backwards)
+    _check(lay, lambda Pt, x, m, c: R.hyper_layer(Pt, x, m, N, H, Z, clip, backwards),
+           P, b['x'], b['mask'])
+
+
+def test_softmax_ce_and_adam():
+    rng = np.random.default_rng(15)
+    lg = rng.standard_normal((B, T, C)) * 3
+    b = make_batch(rng, B, T, D, C)
+    cost, s, pred, dl = O.softmax_ce(lg, b['y'], b['mask'].astype(np.float64))
+    lt = torch.tensor(lg, requires_grad=True)
+    lp = torch.log_softmax(lt, -1)
+    ce = -(lp.gather(2, torch.tensor(b['y'], dtype=torch.int64).unsqueeze(-1))[:, :, 0]
+           * torch.tensor(b['mask'], dtype=torch.float64))
+    (ce.sum() / B).backward()
+    np.testing.assert_allclose(s, ce.sum().item(), rtol=1e-12)
+    np.testing.assert_allclose(dl, lt.grad.numpy(), rtol=1e-10, atol=1e-12)
+    assert (pred == lg.argmax(-1)).all()
+    # Adam vs torch.optim.Adam (same formula: libs/lasagne_libs/updates.py:587-617)
+    p0 = rng.standard_normal((4, 3)); g = rng.standard_normal((4, 3))
+    p = [p0.copy()]; m = [np.zeros_like(p0)]; v = [np.zeros_like(p0)]
+    pt = torch.tensor(p0.copy(), requires_grad=True)
+    opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    t = 0
+    for _ in range(3):
+        t = O.adam_step(p, [g], m, v, t)
+        pt.grad = torch.tensor(g); opt.step()
+    # torch puts eps inside the bias-corrected denominator; difference is O(eps) relative
+    np.testing.assert_allclose(p[0], pt.detach().numpy(), rtol=1e-6)
+
+
+def test_finite_difference_hyper():
+    """Central differences on a scalar loss through the HyperLSTM layer (no clipping)."""
+    rng = np.random.default_rng(16)
+    P = make_params(rng, specs.hyper_params(D, N, H, Z), perturb=0.3)
+    b = make_batch(rng, 2, 4, D, C, lengths=[4, 3])
+    w = rng.standard_normal((2, 4, N))
+    x = b['x'].astype(np.float64); m = b['mask'].astype(np.float64)
+
+    def loss(Pd):
+        return (O.HyperLSTMLayerO(Pd, N, H, Z).forward(x, m) * w).sum()
+    lay = O.HyperLSTMLayerO(P, N, H, Z)
+    lay.forward(x, m); lay.backward(w)
+    for name in ('W_hz_fg', 'W_hhat_x_c', 'W_xhat_ig', 'b_0_og', 'W_h_c'):
+        idx = tuple(rng.integers(0, s) for s in P[name].shape)
+        Pp = {k: v.copy() for k, v in P.items()}; Pm = {k: v.copy() for k, v in P.items()}
+        Pp[name][idx] += 1e-6; Pm[name][idx] -= 1e-6
+        fd = (loss(Pp) - loss(Pm)) / 2e-6
+        np.testing.assert_allclose(lay.grads[name][idx], fd, rtol=1e-5, atol=1e-8)
