@@ -1,0 +1,95 @@
+"""ctypes binding of the C-ABI in include/asr_amd.h.  Loading fails loudly: there is no fallback
+path -- every op of the package runs through libasr_amd.so."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libasr_amd.so')
+
+ERR = {0: 'ASR_OK', -1: 'ASR_ERR_ARG', -2: 'ASR_ERR_LAUNCH', -3: 'ASR_ERR_WS', -4: 'ASR_ERR_TIMEOUT'}
+
+fp = C.c_void_p          # device pointers travel as integers
+i32 = C.c_int
+f32 = C.c_float
+sz = C.c_size_t
+
+
+class LstmDir(C.Structure):
+    _fields_ = [('reverse', i32), ('xin', fp), ('wpack', fp), ('alpha_hid', fp), ('beta_hid', fp),
+                ('alpha_c', fp), ('beta_c', fp), ('c0', fp), ('r0', fp), ('r_out', fp), ('ld_r', i32),
+                ('gates', fp), ('cst', fp), ('ahat', fp), ('rs_a', fp), ('chat', fp), ('rs_c', fp),
+                ('dr_ext', fp), ('ld_dr', i32), ('dG', fp), ('dA', fp), ('dOut', fp)]
+
+
+class LstmScanDesc(C.Structure):
+    _fields_ = [('T', i32), ('B', i32), ('N', i32), ('ndir', i32), ('ln_kind', i32), ('cell_ln', i32),
+                ('grad_clip', f32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
+                ('dir', LstmDir * 2)]
+
+
+class HyperDir(C.Structure):
+    _fields_ = [('reverse', i32), ('xproj', fp), ('xhproj', fp), ('wpack', fp),
+                ('cvec', fp), ('r_out', fp), ('ld_r', i32), ('hh_out', fp),
+                ('gates', fp), ('cst', fp), ('hgates', fp), ('hcst', fp), ('aD', fp),
+                ('dr_ext', fp), ('ld_dr', i32), ('dXp', fp), ('dXh', fp), ('dA', fp), ('dD', fp)]
+
+
+class HyperScanDesc(C.Structure):
+    _fields_ = [('T', i32), ('B', i32), ('N', i32), ('H', i32), ('ndir', i32), ('grad_clip', f32),
+                ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32), ('dir', HyperDir * 2)]
+
+
+_SIGS = {
+    'asr_gemm_f32': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp]),
+    'asr_swap01': (i32, [fp, fp, i32, i32, i32, i32, i32, fp]),
+    'asr_ln_rows_fwd': (i32, [fp, i32, i32, fp, i32, fp, fp, i32, fp, fp, fp, fp, fp]),
+    'asr_ln_rows_bwd': (i32, [fp, i32, i32, fp, fp, fp, i32, fp, fp]),
+    'asr_colreduce_ws_bytes': (sz, [i32, i32]),
+    'asr_colreduce': (i32, [fp, i32, fp, i32, i32, i32, i32, fp, i32, fp, sz, fp]),
+    'asr_bias_act': (i32, [fp, fp, i32, i32, i32, fp]),
+    'asr_act_bwd': (i32, [fp, fp, i32, i32, i32, fp]),
+    'asr_rowscale': (i32, [fp, i32, fp, i32, i32, fp, i32, i32, i32, fp]),
+    'asr_masked_mean': (i32, [fp, fp, i32, i32, i32, fp, fp]),
+    'asr_masked_mean_tanh_bwd': (i32, [fp, fp, fp, i32, i32, i32, fp, fp]),
+    'asr_softmax_ce': (i32, [fp, i32, i32, i32, fp, i32, i32, fp, i32, i32, f32, fp, fp, fp, fp, i32,
+                             fp, fp]),
+    'asr_reduce_sum': (i32, [fp, sz, fp, i32, fp]),
+    'asr_adam_step': (i32, [fp, fp, fp, fp, sz, f32, f32, f32, f32, fp, i32, fp, fp]),
+    'asr_sqsum': (i32, [fp, sz, fp, i32, fp, fp]),
+    'asr_lstm_pack_floats': (sz, [i32, i32]),
+    'asr_lstm_pack_w': (i32, [fp, i32, i32, fp, fp]),
+    'asr_lstm_scan_ws_bytes': (sz, [i32, i32, i32, i32, i32]),
+    'asr_lstm_scan_fwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),
+    'asr_lstm_scan_bwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),
+    'asr_scan_status': (i32, [fp, i32]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('asr_amd: %s is missing -- build it with `python -m asr_amd.build` '
+                               '(there is no CPU fallback)' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)      # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class AsrError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AsrError('%s failed: %s (%d)' % (what, ERR.get(rc, '?'), rc))

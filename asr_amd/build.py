@@ -1,0 +1,42 @@
+"""Builds the C-ABI shared library asr_amd/libasr_amd.so from the HIP sources for gfx950.
+hipcc cross-compiles without a GPU.  Run:  python -m asr_amd.build"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libasr_amd.so')
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def build(force=False, verbose=True):
+    srcs = sources()
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in deps):
+        return LIB
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + '.o'
+        objs.append(o)
+        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-value',
+               '-c', s, '-o', o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+        if verbose and out.strip():
+            sys.stderr.write(out.decode())
+    cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,154 @@
+// K1: exact-fp32 MFMA GEMM for the all-timestep projections and the weight-gradient contractions.
+//   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C  (+ bias[N] broadcast over rows)
+// op = identity or transpose, row-major storage with leading dimensions.  Arithmetic is
+// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain, no reduced precision).
+// Tile: 128x128x16 per 256-thread workgroup, 2x2 waves, each wave 2x2 MFMA tiles of 32x32.
+// LDS images are k-major (As[k][m], Bs[k][n]) so that every MFMA operand read is a conflict-free
+// ds_read_b32 of 32 consecutive floats per lane half; double-buffered.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define LDSP 132   // padded row (floats): 128 + 4 keeps 16-B alignment and breaks bank aliasing
+
+// element (r,c) of op(X): X stored row-major with leading dim ld; if TR, op(X)[r][c] = X[c][r]
+template <bool TR>
+__device__ __forceinline__ float ldg_op(const float* X, int ld, int r, int c, int R, int C) {
+    if (r >= R || c >= C) return 0.0f;
+    return TR ? X[(size_t)c * ld + r] : X[(size_t)r * ld + c];
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, float alpha,
+                                                        const float* __restrict__ A, int lda,
+                                                        const float* __restrict__ B, int ldb,
+                                                        float beta, float* __restrict__ C, int ldc,
+                                                        const float* __restrict__ bias, int ntn) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDSP];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDSP];
+
+    // XCD-aware tile order: blocks b and b+8 share an L2; give each XCD a contiguous strip of
+    // tiles along N so the A row-panel is re-used from that L2.
+    int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        int q = nblk / 8, r = nblk % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;       // 2x2 waves, each 64x64
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // staging registers: each thread moves 8 A and 8 B elements per K-tile
+    float ra[8], rb[8];
+    auto load_tiles = [&](int k0) {
+        // A tile: BM x BK.  Thread mapping chosen so that global reads are contiguous for the
+        // stored layout: !TA -> consecutive threads along k (row contiguous); TA -> along m.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int idx = e * 256 + tid;
+            int mm, kk;
+            if (TA) { mm = idx % BM; kk = idx / BM; } else { kk = idx % BK; mm = idx / BK; }
+            ra[e] = ldg_op<TA>(A, lda, m0 + mm, k0 + kk, M, K);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int idx = e * 256 + tid;
+            int nn, kk;
+            if (TB) { kk = idx % BK; nn = idx / BK; } else { nn = idx % BN; kk = idx / BN; }
+            rb[e] = ldg_op<TB>(B, ldb, k0 + kk, n0 + nn, K, N);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int idx = e * 256 + tid;
+            int mm, kk;
+            if (TA) { mm = idx % BM; kk = idx / BM; } else { kk = idx % BK; mm = idx / BK; }
+            As[buf][kk][mm] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int idx = e * 256 + tid;
+            int nn, kk;
+            if (TB) { kk = idx % BK; nn = idx / BK; } else { nn = idx % BN; kk = idx / BN; }
+            Bs[buf][kk][nn] = rb[e];
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        const int lr = lane & 31, lk = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 2) {
+            float a0 = As[buf][ks + lk][wm * 64 + lr];
+            float a1 = As[buf][ks + lk][wm * 64 + 32 + lr];
+            float b0 = Bs[buf][ks + lk][wn * 64 + lr];
+            float b1 = Bs[buf][ks + lk][wn * 64 + 32 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store_tiles(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < M) {
+                    float* p = C + (size_t)row * ldc + col;
+                    float v = alpha * acc[i][j][e] + bv;
+                    if (beta != 0.0f) v += beta * (*p);
+                    *p = v;
+                }
+            }
+        }
+}
+
+extern "C" int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                            int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                            const float* bias, hipStream_t stream) {
+    if (M < 0 || N < 0 || K < 0 || !C) return ASR_ERR_ARG;
+    if (M == 0 || N == 0) return ASR_OK;
+    if (K > 0 && (!A || !B)) return ASR_ERR_ARG;
+    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    dim3 grid(ntm * ntn), block(256);
+#define LAUNCH(TA_, TB_)                                                                         \
+    hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, block, 0, stream, M, N, K, alpha, A, lda, \
+                       B, ldb, beta, C, ldc, bias, ntn)
+    if (!transA && !transB) LAUNCH(false, false);
+    else if (!transA && transB) LAUNCH(false, true);
+    else if (transA && !transB) LAUNCH(true, false);
+    else LAUNCH(true, true);
+#undef LAUNCH
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

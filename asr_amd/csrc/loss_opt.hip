@@ -1,0 +1,189 @@
+// K3: fused framewise log-softmax / cross-entropy / argmax(FER) / dlogits  (HBM-bound: one pass over
+//     the logits from HBM, re-reads served by L2).
+//     Restates libs/comp_graph_utils.py:29-45 and scripts/hypernets/exp_prj_ln_lstm_fix.py:84-95.
+// K4: Adam (libs/lasagne_libs/updates.py:587-617) fused with the squared gradient norm
+//     (libs/comp_graph_utils.py:77).
+#include "common.h"
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax amax_(ArgMax a, ArgMax b) {
+    // first-occurrence tie break like numpy / Theano argmax
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+// rows are time-major r = t*B + b.  targets / masks are addressed with explicit strides so that the
+// caller's batch-major (B,T) arrays are used as they are.
+// out_mode: 0 none, 1 log-posteriors, 2 probabilities; written batch-major out[b][t][c].
+__global__ __launch_bounds__(256) void softmax_ce_kernel(
+    const float* __restrict__ logits, int C, int B, int T, const int* __restrict__ target, int tgt_sb,
+    int tgt_st, const float* __restrict__ tmask, int msk_sb, int msk_st, float scale,
+    float* __restrict__ dlogits, float* __restrict__ row_ce, float* __restrict__ row_ok,
+    int* __restrict__ pred, int out_mode, float* __restrict__ out) {
+    __shared__ float smf[4];
+    __shared__ int smi[4];
+    const size_t r = blockIdx.x;
+    const int t = (int)(r / B), b = (int)(r % B);
+    const float* lr = logits + r * C;
+    ArgMax am{-INFINITY, 0x7fffffff};
+    for (int c = threadIdx.x; c < C; c += 256) am = amax_(am, ArgMax{lr[c], c});
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax ot{__shfl_xor(am.v, o), __shfl_xor(am.i, o)};
+        am = amax_(am, ot);
+    }
+    if ((threadIdx.x & 63) == 0) { smf[threadIdx.x >> 6] = am.v; smi[threadIdx.x >> 6] = am.i; }
+    __syncthreads();
+    am = ArgMax{smf[0], smi[0]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) am = amax_(am, ArgMax{smf[w], smi[w]});
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += __expf(lr[c] - am.v);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) smf[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = smf[0] + smf[1] + smf[2] + smf[3];
+    const float lse = logf(s);
+    const int y = target ? target[(size_t)b * tgt_sb + (size_t)t * tgt_st] : -1;
+    const float m = tmask ? tmask[(size_t)b * msk_sb + (size_t)t * msk_st] : 1.0f;
+    if (threadIdx.x == 0) {
+        if (row_ce) row_ce[r] = (y >= 0 && y < C) ? -(lr[y] - am.v - lse) * m : 0.f;
+        if (row_ok) row_ok[r] = (am.i == y) ? m : 0.f;
+        if (pred) pred[(size_t)b * T + t] = am.i;
+    }
+    if (dlogits) {
+        const float g = m * scale;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float p = __expf(lr[c] - am.v - lse);
+            dlogits[r * C + c] = (p - (c == y ? 1.f : 0.f)) * g;
+        }
+    }
+    if (out_mode) {
+        float* orow = out + ((size_t)b * T + t) * C;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float lp = lr[c] - am.v - lse;
+            orow[c] = out_mode == 1 ? lp : __expf(lp);
+        }
+    }
+}
+
+extern "C" int asr_softmax_ce(const float* logits, int C, int B, int T, const int* target, int tgt_sb,
+                              int tgt_st, const float* tmask, int msk_sb, int msk_st, float scale,
+                              float* dlogits, float* row_ce, float* row_ok, int* pred, int out_mode,
+                              float* out, hipStream_t stream) {
+    if (C <= 0 || B < 0 || T < 0 || !logits) return ASR_ERR_ARG;
+    if (out_mode && !out) return ASR_ERR_ARG;
+    if ((dlogits || row_ce || row_ok) && !target) return ASR_ERR_ARG;
+    size_t rows = (size_t)B * T;
+    if (!rows) return ASR_OK;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)rows), dim3(256), 0, stream, logits, C, B, T,
+                       target, tgt_sb, tgt_st, tmask, msk_sb, msk_st, scale, dlogits, row_ce, row_ok,
+                       pred, out_mode, out);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// deterministic single-workgroup sum (n up to a few 1e5): out[0] = sum x
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ x, size_t n,
+                                                          float* __restrict__ out, int do_sqrt) {
+    __shared__ double sm[16];
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) acc += (double)x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += sm[w];
+        out[0] = do_sqrt ? (float)sqrt(tot) : (float)tot;
+    }
+}
+extern "C" int asr_reduce_sum(const float* x, size_t n, float* out, int do_sqrt, hipStream_t stream) {
+    if (!x || !out) return ASR_ERR_ARG;
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, stream, x, n, out, do_sqrt);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// ---------------------------------------------------------------- Adam + grad-norm^2 partials
+#define ADAM_BLOCKS 1024
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   size_t n, float a_t, float b1, float b2, float eps,
+                                                   float* __restrict__ sq_part) {
+    __shared__ float sm[4];
+    float sq = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i], pv = ((f32x4*)p)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sq += gv[e] * gv[e];
+            mv[e] = b1 * mv[e] + (1.f - b1) * gv[e];
+            vv[e] = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
+            pv[e] = pv[e] - a_t * mv[e] / (sqrtf(vv[e]) + eps);
+        }
+        ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv; ((f32x4*)p)[i] = pv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        size_t i = n4 * 4 + threadIdx.x;
+        float gv = g[i];
+        sq += gv * gv;
+        float mv = b1 * m[i] + (1.f - b1) * gv;
+        float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv; v[i] = vv;
+        p[i] = p[i] - a_t * mv / (sqrtf(vv) + eps);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0 && sq_part) sq_part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// grads_norm_out[0] = sqrt(sum g^2) (or the plain sum when want_sqrt == 0, the TBPTT trainer's
+// output, libs/comp_graph_utils.py:111).  ws must hold ADAM_BLOCKS floats.
+extern "C" int asr_adam_step(float* p, const float* g, float* m, float* v, size_t n, float a_t, float b1,
+                             float b2, float eps, float* grads_norm_out, int want_sqrt, float* ws,
+                             hipStream_t stream) {
+    if (!p || !g || !m || !v) return ASR_ERR_ARG;
+    if (grads_norm_out && !ws) return ASR_ERR_ARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return ASR_ERR_ARG;
+    if (n == 0) return ASR_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, stream, p, g, m, v, n, a_t, b1, b2,
+                       eps, grads_norm_out ? ws : nullptr);
+    ASR_CHECK_LAUNCH();
+    if (grads_norm_out) {
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, stream, ws, (size_t)ADAM_BLOCKS,
+                           grads_norm_out, want_sqrt);
+        ASR_CHECK_LAUNCH();
+    }
+    return ASR_OK;
+}
+
+// sum of squares only (used when gradients are all-reduced first and for tests)
+__global__ __launch_bounds__(256) void sqsum_kernel(const float* __restrict__ g, size_t n,
+                                                    float* __restrict__ part) {
+    __shared__ float sm[4];
+    float sq = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        sq += g[i] * g[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+extern "C" int asr_sqsum(const float* g, size_t n, float* out, int want_sqrt, float* ws,
+                         hipStream_t stream) {
+    if (!g || !out || !ws) return ASR_ERR_ARG;
+    hipLaunchKernelGGL(sqsum_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, stream, g, n, ws);
+    ASR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, stream, ws, (size_t)ADAM_BLOCKS, out,
+                       want_sqrt);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

@@ -1,0 +1,95 @@
+// Device-side primitives shared by the persistent recurrent-scan kernels.
+//
+// A "group" = the G workgroups that cooperate on one layer-direction (x one chunk of <= 16 batch
+// rows).  Each workgroup owns UT tiles of 4 units (= 16 gate columns in the engine's gate-
+// interleaved column order  col = unit*4 + gate) and keeps its slice of the recurrent matrix in LDS
+// for the whole sequence.  Between dependent phases the group exchanges small vectors through
+// global memory with the placement-independent protocol of cdna_hip_programming.md Guideline 16:
+//   producer : payload stored write-through (sc1), every storing wave drains vmcnt(0), workgroup
+//              barrier, ONE lane adds 1 to the group's monotonic arrival counter (agent scope);
+//   consumer : ONE lane polls the counter with sc1 loads until it reaches epoch*G, workgroup barrier,
+//              then EVERY load of the handed-off bytes is an sc1 load (no L1 involvement).
+// Every spin is bounded by a wall-clock deadline; on expiry the group's abort word is raised, every
+// workgroup leaves its time loop, and the host reports ASR_ERR_TIMEOUT from asr_scan_status().
+#pragma once
+#include "common.h"
+
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+
+#define SYNC_STRIDE 32          // u32 words per group (128 B): [0] arrivals, [1] abort
+#define SCAN_DEADLINE_TICKS 2000000000ull   // 20 s of s_memrealtime (100 MHz)
+
+struct GroupSync {
+    unsigned* words;            // this group's sync line
+    unsigned G;                 // workgroups in the group
+    unsigned epoch;             // exchanges completed so far (uniform across the group)
+    unsigned long long deadline;
+    int* lds_flag;              // one LDS int for broadcasting the poll result
+};
+
+__device__ __forceinline__ void group_publish(GroupSync& gs) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its sc1 stores
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(gs.words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// returns false when the group aborted (timeout somewhere): caller must leave its loop
+__device__ __forceinline__ bool group_wait(GroupSync& gs) {
+    gs.epoch += 1;
+    const unsigned target = gs.epoch * gs.G;
+    if (threadIdx.x == 0) {
+        int good = 1;
+        for (;;) {
+            unsigned long long v = __hip_atomic_load((unsigned long long*)gs.words, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32)) { good = 0; break; }
+            if ((unsigned)v >= target) break;
+            if (__builtin_amdgcn_s_memrealtime() > gs.deadline) {
+                __hip_atomic_store(gs.words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *gs.lds_flag = good;
+    }
+    __syncthreads();
+    const int ok = *gs.lds_flag;
+    __syncthreads();            // flag may be rewritten by the next wait
+    return ok != 0;
+}
+
+// 16-byte sc1 load / store of exchanged payload (buffer_load/store_dwordx4 ... sc1)
+__device__ __forceinline__ f32x4 ld_sc1_f4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ void st_sc1_f4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, f32x4 f) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), rs, byte_off, 0, 16);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+// two floats as ONE aligned 8-byte sc1 store / load
+__device__ __forceinline__ void st_sc1_f2(float* p, float a, float b) {
+    unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ld_sc1_f2(const float* p, float& a, float& b) {
+    unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)v);
+    b = __uint_as_float((unsigned)(v >> 32));
+}
+
+// sum over the 4 lanes that share a batch row inside one 16x16 tile (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float sum_q(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

@@ -1,0 +1,598 @@
+// K2 (LSTM family): persistent recurrent scan, forward and BPTT, for
+//   libs/lhuclstm_layers.py:73-130 (LSTMLayer / TBPTTLSTMLayer / LHUC base recurrence),
+//   libs/lasagne_libs/recurrent_layers.py:437-498 (ProjectLSTMLayer), :707-763
+//   (LayerNormProjectLSTMLayer), :1237-1289 (InputCondLayerNormProjectLSTMLayer).
+//
+// What the kernel sees (prepared by the host side, see asr_amd/engine.py):
+//   * xin (T,B,4N): everything on the input side of the gate pre-activation, already including the
+//     bias and (for LN variants) the input layer norm  -- not recurrent, so hoisted out of the loop.
+//   * the recurrent matrix with the output projection folded in, W' = W_p . W_h (N x 4N), so the
+//     recurrent state is r_t = o * tanh(outcell) (N wide) for every variant and the step needs ONE
+//     all-gather of r; the projected output h_t = r_t . W_p is one large MFMA GEMM after the scan.
+//   * gate-interleaved columns: col = unit*4 + gate (gate order i,f,c,o).
+// Each workgroup owns UT tiles of 4 units, keeps its W' slice resident in LDS as MFMA A-fragments
+// for all T steps, computes  a^T[16 cols x 16 batch] = W'^T . r^T  with v_mfma_f32_16x16x4_f32
+// (4 waves split K), and fuses LN statistics, gates, cell update, masking and the saves for BPTT
+// into the step.  One launch covers both directions (and several 16-row batch chunks).
+#include "scan_common.h"
+#include <stdlib.h>
+
+struct LstmDir {
+    int reverse;
+    const float* xin;        // (T,B,4N)
+    const float* wpack;      // fwd: asr_lstm_pack_w(...,0)   bwd: asr_lstm_pack_w(...,1)
+    const float* alpha_hid;  // (4N) or (B,4N) when ln_kind==2
+    const float* beta_hid;   // (4N) or null
+    const float* alpha_c;    // (N)
+    const float* beta_c;     // (N)
+    const float* c0;         // (B,N) or null
+    const float* r0;         // (B,N) or null
+    float* r_out;            // (T,B,ld_r) state r after each step (time order)
+    int ld_r;
+    float* gates;            // (T,B,4N) post-activation i,f,g,o       (null: inference)
+    float* cst;              // (T,B,N)  cell state after each step   (required)
+    float* ahat;             // (T,B,4N) normalised recurrent pre-activation (LN)
+    float* rs_a;             // (T,B)
+    float* chat;             // (T,B,N)  normalised cell (cell LN)
+    float* rs_c;             // (T,B)
+    // backward only
+    const float* dr_ext;     // (T,B,ld_dr) dLoss/d r_t from the layers above
+    int ld_dr;
+    float* dG;               // (T,B,4N) clipped gradient wrt the gate pre-activations
+    float* dA;               // (T,B,4N) gradient wrt a_t = r_{t-1}.W'   (== dG when no LN)
+    float* dOut;             // (T,B,N)  clipped gradient wrt outcell (cell LN only)
+};
+
+struct LstmScanArgs {
+    int T, B, N, UT, G, KS, KSP, KT;
+    int ndir, nchunk, chunk0;
+    int ln_kind;             // 0 none, 1 static alpha[,beta], 2 per-sample alpha
+    int cell_ln;
+    float clip;
+    const float* mask; int msb, mst;
+    LstmDir d[2];
+    unsigned* sync;          // [ngroups][SYNC_STRIDE]
+    float* rex;              // [ngroups][2][KS][64]
+    float* sta;              // [ngroups][2][KS][32]
+    float* stc;              // [ngroups][2][KS][32]
+    float* dex;              // [ngroups][2][KS dst][G src][64]      (backward)
+};
+
+// ------------------------------------------------------------------------------------------------
+// weight packing.  W (N x 4N) row-major, gate-interleaved columns.
+//  mode 0 (forward A-fragments):  out[tile][s4][l][e] = W[4*(4*s4+e) + (l>>4)][tile*16 + (l&15)]
+//  mode 1 (backward A-fragments): out[tile][kt][l][e] = W[kt*16 + (l&15)][tile*16 + 4*e + (l>>4)]
+// rows/steps beyond N are zero.
+__global__ void lstm_pack_kernel(const float* __restrict__ W, int N, int KS, int KSP, int KT, int mode,
+                                 float* __restrict__ out) {
+    const int per_tile = mode == 0 ? KSP * 64 : KT * 256;
+    const size_t tot = (size_t)KS * per_tile;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int tile = (int)(i / per_tile);
+        const int r = (int)(i % per_tile);
+        const int e = r & 3, l = (r >> 2) & 63, blk = r >> 8;
+        int row, col;
+        if (mode == 0) { row = 4 * (4 * blk + e) + (l >> 4); col = tile * 16 + (l & 15); }
+        else           { row = blk * 16 + (l & 15);          col = tile * 16 + 4 * e + (l >> 4); }
+        out[i] = row < N ? W[(size_t)row * 4 * N + col] : 0.0f;
+    }
+}
+
+static inline void lstm_dims(int N, int* KS, int* KSP, int* KT) {
+    *KS = N / 4;
+    *KSP = ((*KS + 15) / 16) * 16;
+    *KT = (N + 15) / 16;
+}
+
+extern "C" size_t asr_lstm_pack_floats(int N, int mode) {
+    int KS, KSP, KT;
+    lstm_dims(N, &KS, &KSP, &KT);
+    return mode == 0 ? (size_t)KS * KSP * 64 : (size_t)KS * KT * 256;
+}
+
+extern "C" int asr_lstm_pack_w(const float* W, int N, int mode, float* out, hipStream_t stream) {
+    if (!W || !out || N <= 0 || (N & 3)) return ASR_ERR_ARG;
+    int KS, KSP, KT;
+    lstm_dims(N, &KS, &KSP, &KT);
+    size_t tot = asr_lstm_pack_floats(N, mode);
+    int grid = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(grid), dim3(256), 0, stream, W, N, KS, KSP, KT, mode, out);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Combine per-tile (mean, M2) statistics (equal counts cnt per tile) into the row mean / rstd over
+// all KS tiles.  Called by a whole epilogue wave; lane (q,bl) returns the stats of batch row bl.
+__device__ __forceinline__ void combine_stats(const float* st, int KS, int lane, float cnt,
+                                              float& mean, float& rstd) {
+    const int q = lane >> 4, bl = lane & 15;
+    float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
+    for (int s = q; s < KS; s += 4) {
+        float mj, M2j;
+        ld_sc1_f2(st + s * 32 + bl * 2, mj, M2j);
+        sm += mj; sm2 += mj * mj; sM2 += M2j;
+    }
+    sm = sum_q(sm); sm2 = sum_q(sm2); sM2 = sum_q(sM2);
+    mean = sm / KS;
+    float between = sm2 - KS * mean * mean;
+    if (between < 0.f) between = 0.f;
+    const float var = (sM2 + cnt * between) / (cnt * KS);
+    rstd = 1.0f / sqrtf(var + ASR_EPS);
+}
+// plain sums (backward LN: sum dxh, sum dxh*xhat) over all tiles
+__device__ __forceinline__ void combine_sums(const float* st, int KS, int lane, float& s1, float& s2) {
+    const int q = lane >> 4, bl = lane & 15;
+    float a = 0.f, b = 0.f;
+    for (int s = q; s < KS; s += 4) {
+        float x, y;
+        ld_sc1_f2(st + s * 32 + bl * 2, x, y);
+        a += x; b += y;
+    }
+    s1 = sum_q(a); s2 = sum_q(b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int UT>
+__global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                   // [UT][KSP/4][64][4]
+    float* red = Wl + (size_t)UT * A.KSP * 64;          // [UT][4 waves][64][4]
+    int* flag = (int*)(red + UT * 4 * 256);
+
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
+    const int grp = chunk * A.ndir + dir;
+    const LstmDir& D = A.d[dir];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, bl = lane & 15;
+    const int b0 = chunk * 16;
+    const int b = b0 + bl;
+    const bool bvalid = b < A.B;
+    const int N = A.N, KS = A.KS, KSP = A.KSP, T = A.T, B = A.B;
+
+    GroupSync gs;
+    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
+    gs.G = A.G; gs.epoch = 0;
+    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
+    gs.lds_flag = flag;
+
+    // resident weights
+    {
+        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * UT * KSP * 64);
+        f32x4* dst = (f32x4*)Wl;
+        for (int i = tid; i < UT * KSP * 16; i += 256) dst[i] = src[i];
+    }
+    float* rex = A.rex + (size_t)grp * 2 * KS * 64;
+    float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 32 : nullptr;
+    float* stc = A.stc ? A.stc + (size_t)grp * 2 * KS * 32 : nullptr;
+
+    // epilogue-wave state: wave ut < UT owns tile (j*UT+ut); lane (q,bl) owns unit q of it for row bl
+    const int tile = j * UT + (wave < UT ? wave : 0);
+    const int unit = tile * 4 + q;
+    const int col4 = unit * 4;
+    float c = 0.f, r = 0.f;
+    if (wave < UT) {
+        if (bvalid && D.c0) c = D.c0[(size_t)b * N + unit];
+        if (bvalid && D.r0) r = D.r0[(size_t)b * N + unit];
+        st_sc1(rex + (size_t)tile * 64 + lane, r);       // parity 0 holds r_{-1}
+    }
+    float ac_u = 1.f, bc_u = 0.f;
+    if (A.cell_ln) { ac_u = D.alpha_c[unit]; bc_u = D.beta_c[unit]; }
+    group_publish(gs);
+
+    const int s4_per_wave = KSP / 16;                    // groups of 4 MFMA k-steps per wave
+    for (int step = 0; step < T; ++step) {
+        const int t = D.reverse ? T - 1 - step : step;
+        const int par = step & 1;
+        const size_t row = (size_t)t * B + b;
+        // prefetch what does not depend on the exchange
+        f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
+        float m = 0.f;
+        if (wave < UT && bvalid) {
+            x4 = *(const f32x4*)(D.xin + row * 4 * N + col4);
+            m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
+        }
+        if (!group_wait(gs)) break;
+
+        // a^T tile partials over this wave's K quarter; B operand straight from the exchange buffer
+        const float* rp = rex + (size_t)par * KS * 64;
+        f32x4 acc0[UT], acc1[UT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) { acc0[u] = f32x4{0, 0, 0, 0}; acc1[u] = f32x4{0, 0, 0, 0}; }
+        for (int g4 = 0; g4 < s4_per_wave; ++g4) {
+            const int s4 = wave * s4_per_wave + g4;
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int s = s4 * 4 + e;
+                bv[e] = s < KS ? ld_sc1(rp + (size_t)s * 64 + lane) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                const f32x4 av = *(const f32x4*)(Wl + (((size_t)u * (KSP / 4) + s4) * 64 + lane) * 4);
+                acc0[u] = mfma4(av[0], bv[0], acc0[u]);
+                acc1[u] = mfma4(av[1], bv[1], acc1[u]);
+                acc0[u] = mfma4(av[2], bv[2], acc0[u]);
+                acc1[u] = mfma4(av[3], bv[3], acc1[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+            *(f32x4*)(red + ((size_t)(u * 4 + wave) * 64 + lane) * 4) = acc0[u] + acc1[u];
+        __syncthreads();
+
+        f32x4 a4 = {0, 0, 0, 0};
+        if (wave < UT) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(wave * 4 + w) * 64 + lane) * 4);
+        }
+        float rs_a = 0.f;
+        f32x4 ah4 = {0, 0, 0, 0};
+        if (A.ln_kind) {
+            if (wave < UT) {       // per-tile mean / M2 over its 16 columns, per batch row
+                const float mj = sum_q(a4[0] + a4[1] + a4[2] + a4[3]) * (1.0f / 16.0f);
+                f32x4 dlt = a4 - mj;
+                const float M2 = sum_q(dlt[0] * dlt[0] + dlt[1] * dlt[1] + dlt[2] * dlt[2] + dlt[3] * dlt[3]);
+                if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 32 + bl * 2, mj, M2);
+            }
+            group_publish(gs);
+            if (!group_wait(gs)) break;
+            if (wave < UT) {
+                float mean;
+                combine_stats(sta + (size_t)par * KS * 32, KS, lane, 16.0f, mean, rs_a);
+                ah4 = (a4 - mean) * rs_a;
+            }
+        }
+        float chat_v = 0.f, rs_c = 0.f, c_new = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
+        if (wave < UT) {
+            f32x4 pre;
+            if (A.ln_kind) {
+                const float* al = D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4;
+                const f32x4 al4 = *(const f32x4*)al;
+                pre = x4 + al4 * ah4;
+                if (D.beta_hid) pre += *(const f32x4*)(D.beta_hid + col4);
+            } else {
+                pre = x4 + a4;
+            }
+            ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf_(pre[2]); og = sigmoidf_(pre[3]);
+            c_new = fg * c + ig * gg;
+        }
+        float outcell = c_new;
+        if (A.cell_ln) {
+            if (wave < UT) {       // per-tile stats over its 4 units
+                const float mj = sum_q(c_new) * 0.25f;
+                const float dl = c_new - mj;
+                const float M2 = sum_q(dl * dl);
+                if (q == 0) st_sc1_f2(stc + ((size_t)par * KS + tile) * 32 + bl * 2, mj, M2);
+            }
+            group_publish(gs);
+            if (!group_wait(gs)) break;
+            if (wave < UT) {
+                float mean;
+                combine_stats(stc + (size_t)par * KS * 32, KS, lane, 4.0f, mean, rs_c);
+                chat_v = (c_new - mean) * rs_c;
+                outcell = ac_u * chat_v + bc_u;
+            }
+        }
+        if (wave < UT) {
+            const float r_new = og * tanhf_(outcell);
+            if (m != 0.f) { c = c_new; r = r_new; }
+            st_sc1(rex + ((size_t)(par ^ 1) * KS + tile) * 64 + lane, r);
+            if (bvalid) {
+                D.r_out[row * D.ld_r + unit] = r;
+                D.cst[row * N + unit] = c;
+                if (D.gates) *(f32x4*)(D.gates + row * 4 * N + col4) = f32x4{ig, fg, gg, og};
+                if (A.ln_kind && D.ahat) {
+                    *(f32x4*)(D.ahat + row * 4 * N + col4) = ah4;
+                    if (tile == 0 && q == 0) D.rs_a[row] = rs_a;
+                }
+                if (A.cell_ln && D.chat) {
+                    D.chat[row * N + unit] = chat_v;
+                    if (tile == 0 && q == 0) D.rs_c[row] = rs_c;
+                }
+            }
+        }
+        group_publish(gs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (BPTT).  Walks the forward iteration order in reverse.  Per step and workgroup:
+//   1. sum the partial dr_{t} contributions every workgroup published in the previous step
+//   2. cell / gate gradients for its units (+ LN backward with two small stat exchanges)
+//   3. partial dr_{t-1}[b, all k] = da[b, own cols] . W'[k, own cols]^T  -> publish per destination
+// ------------------------------------------------------------------------------------------------
+template <int UT>
+__global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wb = smem;                                   // [UT][KT][64][4]
+    float* dal = Wb + (size_t)UT * A.KT * 256;          // [UT][16 cols][16 b]
+    float* rsum = dal + UT * 256;                       // [UT][16 sg][16 b][4]
+    int* flag = (int*)(rsum + UT * 1024);
+
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
+    const int grp = chunk * A.ndir + dir;
+    const LstmDir& D = A.d[dir];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, bl = lane & 15;
+    const int b = chunk * 16 + bl;
+    const bool bvalid = b < A.B;
+    const int N = A.N, KS = A.KS, KT = A.KT, T = A.T, B = A.B, G = A.G;
+
+    GroupSync gs;
+    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
+    gs.G = A.G; gs.epoch = 0;
+    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
+    gs.lds_flag = flag;
+    {
+        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * UT * KT * 256);
+        f32x4* dst = (f32x4*)Wb;
+        for (int i = tid; i < UT * KT * 64; i += 256) dst[i] = src[i];
+    }
+    float* dex = A.dex + (size_t)grp * 2 * KS * G * 64;
+    float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 32 : nullptr;
+    float* stc = A.stc ? A.stc + (size_t)grp * 2 * KS * 32 : nullptr;
+    const __amdgpu_buffer_rsrc_t dex_rs = make_rsrc_(dex, (unsigned)((size_t)2 * KS * G * 64 * 4));
+
+    const int tile = j * UT + (wave < UT ? wave : 0);
+    const int unit = tile * 4 + q;
+    const int col4 = unit * 4;
+    float ac_u = 1.f, bc_u = 0.f;
+    if (A.cell_ln) { ac_u = D.alpha_c[unit]; bc_u = D.beta_c[unit]; }
+    float dc = 0.f, dr_pass = 0.f;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int st = T - 1 - step;                     // forward iteration index
+        const int t = D.reverse ? T - 1 - st : st;
+        const int tprev = D.reverse ? t + 1 : t - 1;     // valid when st > 0
+        const int par = step & 1;
+        const size_t row = (size_t)t * B + b;
+        const size_t rowp = (size_t)tprev * B + b;
+        f32x4 g4 = {0, 0, 0, 0}, ah4 = {0, 0, 0, 0};
+        float m = 0.f, c_new = 0.f, c_prev = 0.f, dre = 0.f, chat_v = 0.f, rs_a = 0.f, rs_c = 0.f;
+        if (wave < UT && bvalid) {
+            m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
+            g4 = *(const f32x4*)(D.gates + row * 4 * N + col4);
+            c_new = D.cst[row * N + unit];
+            c_prev = st > 0 ? D.cst[rowp * N + unit] : (D.c0 ? D.c0[(size_t)b * N + unit] : 0.f);
+            dre = D.dr_ext[row * D.ld_dr + unit];
+            if (A.ln_kind) { ah4 = *(const f32x4*)(D.ahat + row * 4 * N + col4); rs_a = D.rs_a[row]; }
+            if (A.cell_ln) { chat_v = D.chat[row * N + unit]; rs_c = D.rs_c[row]; }
+        }
+        // 1. gather dr contributions published by the previous backward step
+        float dr_sum = 0.f;
+        if (step > 0) {
+            if (!group_wait(gs)) break;
+            const int sg = tid >> 4, f4 = tid & 15;
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                f32x4 acc = {0, 0, 0, 0};
+                const size_t base = (((size_t)(par ^ 1) * KS + (j * UT + u)) * G) * 64;
+                for (int src = sg; src < G; src += 16)
+                    acc += ld_sc1_f4(dex_rs, (unsigned)((base + (size_t)src * 64 + f4 * 4) * 4));
+                *(f32x4*)(rsum + ((size_t)(u * 16 + sg) * 16 + f4) * 4) = acc;
+            }
+            __syncthreads();
+            if (wave < UT) {
+#pragma unroll
+                for (int sgi = 0; sgi < 16; ++sgi) dr_sum += rsum[((size_t)(wave * 16 + sgi) * 16 + bl) * 4 + q];
+            }
+        }
+        // 2. cell / gate gradients
+        const float dr_t = dre + dr_pass + dr_sum;
+        const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
+        const bool on = (m != 0.f);
+        float outcell = c_new;
+        if (A.cell_ln) outcell = ac_u * chat_v + bc_u;
+        const float tc = tanhf_(outcell);
+        float do_ = 0.f, dout = 0.f;
+        if (on) {
+            do_ = dr_t * tc;
+            dout = clipf_(dr_t * og * (1.f - tc * tc), A.clip);
+        }
+        float dcn = dout;
+        if (A.cell_ln) {
+            const float dxh = dout * ac_u;
+            if (wave < UT) {
+                const float s1 = sum_q(dxh), s2 = sum_q(dxh * chat_v);
+                if (q == 0) st_sc1_f2(stc + ((size_t)par * KS + tile) * 32 + bl * 2, s1, s2);
+                if (bvalid && D.dOut) D.dOut[row * N + unit] = dout;
+            }
+            group_publish(gs);
+            if (!group_wait(gs)) break;
+            if (wave < UT) {
+                float s1, s2;
+                combine_sums(stc + (size_t)par * KS * 32, KS, lane, s1, s2);
+                dcn = rs_c * (dxh - s1 / N - chat_v * (s2 / N));
+            }
+        }
+        f32x4 dg4 = {0, 0, 0, 0};
+        if (on) {
+            const float dct = dc + dcn;
+            dg4[0] = clipf_(dct * gg * ig * (1.f - ig), A.clip);
+            dg4[1] = clipf_(dct * c_prev * fg * (1.f - fg), A.clip);
+            dg4[2] = clipf_(dct * ig * (1.f - gg * gg), A.clip);
+            dg4[3] = clipf_(do_ * og * (1.f - og), A.clip);
+            dc = dct * fg;
+            dr_pass = 0.f;
+        } else {
+            dr_pass = dr_t;
+        }
+        f32x4 da4 = dg4;
+        if (wave < UT && bvalid) *(f32x4*)(D.dG + row * 4 * N + col4) = dg4;
+        if (A.ln_kind) {
+            f32x4 dah = {0, 0, 0, 0};
+            if (wave < UT) {
+                const float* al = D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4;
+                dah = dg4 * (*(const f32x4*)al);
+                const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
+                const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
+                if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 32 + bl * 2, s1, s2);
+            }
+            group_publish(gs);
+            if (!group_wait(gs)) break;
+            if (wave < UT) {
+                float s1, s2;
+                combine_sums(sta + (size_t)par * KS * 32, KS, lane, s1, s2);
+                const float m1 = s1 / (4 * N), m2 = s2 / (4 * N);
+                da4 = rs_a * (dah - m1 - ah4 * m2);
+                if (bvalid) *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
+            }
+        }
+        // 3. partial dr_{prev}: B operand needs da[b][col 4e+(l>>4)] -> go through LDS
+        if (wave < UT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dal[(size_t)wave * 256 + (q * 4 + k) * 16 + bl] = da4[k];
+        }
+        __syncthreads();
+        if (step + 1 < T) {
+            for (int kt = wave; kt < KT; kt += 4) {
+                f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    const f32x4 av = *(const f32x4*)(Wb + (((size_t)u * KT + kt) * 64 + lane) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = mfma4(av[e], dal[(size_t)u * 256 + (4 * e + q) * 16 + bl], acc);
+                }
+                const int dst = kt * 4 + q;              // destination tile (units 4*dst .. 4*dst+3)
+                if (dst < KS)
+                    st_sc1_f4(dex_rs, (unsigned)(((((size_t)par * KS + dst) * G + j) * 64 + bl * 4) * 4), acc);
+            }
+            group_publish(gs);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------------
+struct asr_lstm_scan_desc {      // mirrored in include/asr_amd.h
+    int T, B, N, ndir, ln_kind, cell_ln;
+    float grad_clip;
+    const float* mask; int mask_stride_b, mask_stride_t;
+    LstmDir dir[2];
+};
+
+static int pick_ut(int N, int ngroups_per_step) {
+    // smallest UT in {1,2,4} whose grid fits 256 co-resident workgroups
+    for (int ut = 1; ut <= 4; ut *= 2) {
+        if (N % (4 * ut)) continue;
+        if ((N / (4 * ut)) * ngroups_per_step <= 256) return ut;
+    }
+    return 0;
+}
+
+extern "C" size_t asr_lstm_scan_ws_bytes(int T, int B, int N, int ndir, int backward) {
+    (void)T;
+    int KS, KSP, KT;
+    lstm_dims(N, &KS, &KSP, &KT);
+    const int nchunk = (B + 15) / 16;
+    const size_t ng = (size_t)ndir * nchunk;
+    size_t bytes = ng * SYNC_STRIDE * 4;
+    bytes += ng * 2 * KS * 64 * 4;            // rex
+    bytes += 2 * ng * 2 * KS * 32 * 4;        // sta, stc
+    if (backward) bytes += ng * 2 * (size_t)KS * KS * 64 * 4;   // dex (G <= KS)
+    return bytes + 1024;
+}
+
+static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, int backward,
+                            hipStream_t stream) {
+    if (!d || !ws) return ASR_ERR_ARG;
+    if (d->T < 0 || d->B <= 0 || d->N <= 0 || (d->N & 3) || d->ndir < 1 || d->ndir > 2) return ASR_ERR_ARG;
+    if (!d->mask) return ASR_ERR_ARG;
+    for (int k = 0; k < d->ndir; ++k) {
+        const LstmDir& D = d->dir[k];
+        if (!D.wpack || !D.cst) return ASR_ERR_ARG;
+        if (!backward && (!D.xin || !D.r_out)) return ASR_ERR_ARG;
+        if (backward && (!D.gates || !D.dr_ext || !D.dG)) return ASR_ERR_ARG;
+        if (d->ln_kind && (!D.alpha_hid || !D.ahat || !D.rs_a)) return ASR_ERR_ARG;
+        if (d->ln_kind && backward && !D.dA) return ASR_ERR_ARG;
+        if (d->cell_ln && (!D.alpha_c || !D.beta_c || !D.chat || !D.rs_c)) return ASR_ERR_ARG;
+    }
+    if (ws_bytes < asr_lstm_scan_ws_bytes(d->T, d->B, d->N, d->ndir, backward)) return ASR_ERR_WS;
+    if (d->T == 0) return ASR_OK;
+
+    LstmScanArgs A;
+    A.T = d->T; A.B = d->B; A.N = d->N;
+    lstm_dims(d->N, &A.KS, &A.KSP, &A.KT);
+    A.ndir = d->ndir;
+    const int nchunk_total = (d->B + 15) / 16;
+    A.ln_kind = d->ln_kind; A.cell_ln = d->cell_ln; A.clip = d->grad_clip;
+    A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
+    A.d[0] = d->dir[0];
+    A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
+    // chunks per launch limited by co-residency (<= 256 workgroups in flight)
+    int cpl = 256 / (d->ndir * (d->N / 4));
+    int UT = 1;
+    if (cpl >= 1) {
+        if (cpl > nchunk_total) cpl = nchunk_total;
+    } else {
+        cpl = 1;
+        UT = pick_ut(d->N, d->ndir);
+        if (!UT) return ASR_ERR_ARG;     // N too large for a co-resident grid
+    }
+    A.UT = UT; A.G = d->N / (4 * UT);
+
+    char* p = (char*)ws;
+    const size_t ng = (size_t)d->ndir * nchunk_total;
+    A.sync = (unsigned*)p;                         p += ng * SYNC_STRIDE * 4;
+    A.rex = (float*)p;                             p += ng * 2 * A.KS * 64 * 4;
+    A.sta = (float*)p;                             p += ng * 2 * A.KS * 32 * 4;
+    A.stc = (float*)p;                             p += ng * 2 * A.KS * 32 * 4;
+    A.dex = backward ? (float*)p : nullptr;
+    if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
+
+    size_t lds;
+    if (!backward) lds = ((size_t)UT * A.KSP * 64 + UT * 4 * 256) * 4 + 64;
+    else lds = ((size_t)UT * A.KT * 256 + UT * 256 + UT * 1024) * 4 + 64;
+    if (lds > 160 * 1024) return ASR_ERR_ARG;
+
+    for (int c0 = 0; c0 < nchunk_total; c0 += cpl) {
+        const int nc = (nchunk_total - c0 < cpl) ? nchunk_total - c0 : cpl;
+        LstmScanArgs Al = A;
+        Al.nchunk = nc;
+        Al.chunk0 = c0;
+        dim3 grid(A.G, d->ndir, nc), block(256);
+#define LAUNCH_(K, U) \
+        do { hipFuncSetAttribute((const void*)K<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+             hipLaunchKernelGGL((K<U>), grid, block, lds, stream, Al); } while (0)
+        if (!backward) {
+            if (UT == 1) LAUNCH_(lstm_scan_fwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_fwd_kernel, 2);
+            else LAUNCH_(lstm_scan_fwd_kernel, 4);
+        } else {
+            if (UT == 1) LAUNCH_(lstm_scan_bwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_bwd_kernel, 2);
+            else LAUNCH_(lstm_scan_bwd_kernel, 4);
+        }
+#undef LAUNCH_
+        ASR_CHECK_LAUNCH();
+    }
+    return ASR_OK;
+}
+
+extern "C" int asr_lstm_scan_fwd(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return lstm_scan_launch(d, ws, ws_bytes, 0, stream);
+}
+extern "C" int asr_lstm_scan_bwd(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return lstm_scan_launch(d, ws, ws_bytes, 1, stream);
+}
+
+// Host-visible check of the group abort words after the stream has been synchronised by the caller:
+// returns ASR_ERR_TIMEOUT when any group gave up.  `ngroups` = ndir * ceil(B/16).
+extern "C" int asr_scan_status(const void* ws, int ngroups) {
+    if (!ws || ngroups <= 0 || ngroups > 4096) return ASR_ERR_ARG;
+    unsigned* host = (unsigned*)malloc((size_t)ngroups * SYNC_STRIDE * 4);
+    if (!host) return ASR_ERR_ARG;
+    int rc = ASR_OK;
+    if (hipMemcpy(host, ws, (size_t)ngroups * SYNC_STRIDE * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = ASR_ERR_LAUNCH;
+    else
+        for (int g = 0; g < ngroups; ++g)
+            if (host[(size_t)g * SYNC_STRIDE + 1]) rc = ASR_ERR_TIMEOUT;
+    free(host);
+    return rc;
+}

@@ -1,0 +1,690 @@
+"""Execution engine: runs a stacked (bi)directional recurrent acoustic model on one MI355X through
+the C-ABI kernels.  torch supplies device memory and streams; all arithmetic is HIP.
+
+Internal conventions
+  * activations are time-major 2-D matrices (T*B, width), row r = t*B + b;
+  * every 4N-wide gate tensor / weight is gate-interleaved: col = unit*4 + gate;
+  * all trainable parameters live in ONE flat fp32 buffer (`ParamStore.p`) with a same-shaped flat
+    gradient buffer, so Adam, the gradient norm and the data-parallel all-reduce are single passes;
+    `ref_views` give strided views with the reference's per-gate names/shapes for pickles.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib, ops, specs
+from ._lib import check
+
+G4L = specs.GATES_LHUC
+G4R = specs.GATES_REC
+
+
+class Arena(object):
+    """Named, growable device buffers (no per-step allocation once sizes have been seen)."""
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, numel, dtype=torch.float32, zero=False):
+        t = self.bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        v = t[:numel]
+        if zero:
+            v.zero_()
+        return v
+
+    def mat(self, name, rows, cols, zero=False):
+        return self.get(name, rows * cols, zero=zero).view(rows, cols)
+
+
+class ParamStore(object):
+    def __init__(self):
+        self.entries = []      # (key, shape, offset)
+        self.size = 0
+        self.p = None
+        self.g = None
+
+    def add(self, key, shape):
+        n = int(np.prod(shape))
+        self.entries.append((key, tuple(shape), self.size))
+        self.size += (n + 3) // 4 * 4
+        return len(self.entries) - 1
+
+    def materialize(self, device):
+        self.p = torch.zeros(self.size, dtype=torch.float32, device=device)
+        self.g = torch.zeros(self.size, dtype=torch.float32, device=device)
+        self.pv = {}
+        self.gv = {}
+        for key, shape, off in self.entries:
+            n = int(np.prod(shape))
+            self.pv[key] = self.p[off:off + n].view(shape)
+            self.gv[key] = self.g[off:off + n].view(shape)
+
+
+class _PermView(object):
+    """reference tensor (..., 4N) gate-major <-> engine (..., N, 4): copy helpers (not a plain view)."""
+    def __init__(self, E):
+        self.E = E
+
+    def copy_from(self, ref):
+        lead = self.E.shape[:-1]
+        self.E.view(*lead, -1, 4).copy_(ref.view(*lead, 4, -1).transpose(-1, -2))
+
+    def to_ref(self):
+        lead = self.E.shape[:-1]
+        return self.E.view(*lead, -1, 4).transpose(-1, -2).reshape(*lead, -1)
+
+
+class DirParams(object):
+    """Engine tensors of one layer-direction + the mapping to the reference's parameter list."""
+    def __init__(self, store, prefix):
+        self.store = store
+        self.prefix = prefix
+        self.keys = {}
+        self.refmap = []       # (ref_name, engine_key, kind, arg)
+
+    def add(self, name, shape):
+        key = self.prefix + name
+        self.store.add(key, shape)
+        self.keys[name] = key
+
+    def p(self, name):
+        return self.store.pv[self.keys[name]]
+
+    def g(self, name):
+        return self.store.gv[self.keys[name]]
+
+    def has(self, name):
+        return name in self.keys
+
+    def map(self, ref_name, name, kind='same', arg=None):
+        self.refmap.append((ref_name, name, kind, arg))
+
+    def _view(self, E, kind, arg):
+        if kind == 'same':
+            return E
+        if kind == 'gatecols':
+            return E.view(E.shape[0], -1, 4)[:, :, arg]
+        if kind == 'gatevec':
+            return E.view(-1, 4)[:, arg]
+        if kind == 'index':
+            return E[arg]
+        if kind == 'aug_w':                      # (4, H+1, Z): rows < H of gate arg
+            return E[arg, :-1, :]
+        if kind == 'aug_b':
+            return E[arg, -1, :]
+        raise KeyError(kind)
+
+    def load_ref(self, values, grads=False):
+        """values: dict ref_name -> torch tensor (device)."""
+        for ref_name, name, kind, arg in self.refmap:
+            E = self.g(name) if grads else self.p(name)
+            v = values[ref_name]
+            if kind == 'perm4':
+                _PermView(E).copy_from(v)
+            else:
+                self._view(E, kind, arg).copy_(v)
+
+    def dump_ref(self, grads=False):
+        out = []
+        for ref_name, name, kind, arg in self.refmap:
+            E = self.g(name) if grads else self.p(name)
+            v = _PermView(E).to_ref() if kind == 'perm4' else self._view(E, kind, arg)
+            out.append((ref_name, v.detach().contiguous().cpu().numpy()))
+        return out
+
+
+def _mk_lstm_family(store, prefix, kind, D, N, P, use_ln, I=0, F=0, npu=0, npl=0):
+    """Registers engine tensors and the reference mapping for one direction.  P = output width of the
+    recurrence fed back through W_h (0: no projection)."""
+    dp = DirParams(store, prefix)
+    K = P if P else N
+    dp.add('Wx', (D, 4 * N)); dp.add('Wh', (K, 4 * N))
+    if kind in ('lstm', 'lhuc'):                 # libs/lhuclstm_layers.py:32-71
+        dp.add('b', (4 * N,))
+        for g, gn in enumerate(G4L):
+            dp.map('W_h_' + gn, 'Wh', 'gatecols', g); dp.map('W_x_' + gn, 'Wx', 'gatecols', g)
+            dp.map('b_' + gn, 'b', 'gatevec', g)
+        if P:
+            dp.add('Wp', (N, P)); dp.map('W_p', 'Wp')
+        if use_ln:
+            dp.add('a_in', (4 * N,)); dp.add('a_hid', (4 * N,)); dp.add('a_c', (N,)); dp.add('b_c', (N,))
+            dp.map('W_x_alpha', 'a_in', 'perm4'); dp.map('W_h_alpha', 'a_hid', 'perm4')
+            dp.map('W_c_alpha', 'a_c'); dp.map('W_c_beta', 'b_c')
+        if kind == 'lhuc':                       # libs/lhuclstm_layers.py:327-348
+            for i in range(npl + 1):
+                ind = I if i == 0 else npu
+                outd = npu if i < npl else (P if P else N)
+                dp.add('We%d' % i, (ind, outd)); dp.add('be%d' % i, (outd,))
+                dp.map('W_e_h_%d' % i, 'We%d' % i); dp.map('b_e_h_%d' % i, 'be%d' % i)
+    elif kind in ('prj', 'ln_prj'):              # recurrent_layers.py:329-377, :585-647
+        dp.add('b', (4 * N,))
+        for g, gn in enumerate(G4R):
+            dp.map('W_in_to_' + gn, 'Wx', 'gatecols', g); dp.map('W_hid_to_' + gn, 'Wh', 'gatecols', g)
+            dp.map('b_' + gn, 'b', 'gatevec', g)
+        if kind == 'ln_prj':
+            for nm in ('a_in', 'b_in', 'a_hid', 'b_hid'):
+                dp.add(nm, (4 * N,))
+            dp.add('a_c', (N,)); dp.add('b_c', (N,))
+            dp.map('W_alpha_in', 'a_in', 'perm4'); dp.map('W_beta_in', 'b_in', 'perm4')
+            dp.map('W_alpha_hid', 'a_hid', 'perm4'); dp.map('W_beta_hid', 'b_hid', 'perm4')
+            dp.map('W_alpha_cell', 'a_c'); dp.map('W_beta_cell', 'b_c')
+        dp.add('Wp', (N, P)); dp.map('W_hid_prj', 'Wp')
+    elif kind == 'icond_ln_prj':                 # recurrent_layers.py:1115-1188
+        for g, gn in enumerate(G4R):
+            dp.map('W_in_to_' + gn, 'Wx', 'gatecols', g); dp.map('W_hid_to_' + gn, 'Wh', 'gatecols', g)
+        dp.add('Wp', (N, P)); dp.map('W_hid_prj', 'Wp')
+        dp.add('Wc', (I, F)); dp.add('bc', (F,)); dp.map('W_cond_prj', 'Wc'); dp.map('b_cond_prj', 'bc')
+        for nm, rn in (('ai', 'alpha_in'), ('ah', 'alpha_hid'), ('bt', 'beta')):
+            dp.add('W' + nm, (F, 4 * N)); dp.add('b' + nm, (4 * N,))
+            dp.map('W_' + rn, 'W' + nm, 'perm4'); dp.map('b_' + rn, 'b' + nm, 'perm4')
+    else:
+        raise KeyError(kind)
+    return dp
+
+
+class LstmPair(object):
+    """One layer of the stack: a forward direction and optionally a backward direction of the same
+    LSTM-family kind, run by ONE persistent scan launch."""
+    def __init__(self, net, idx, kind, D, N, P, use_ln, clip, ndir, I=0, F=0, npu=0, npl=0,
+                 stateful=False, context=0):
+        self.net = net; self.idx = idx; self.kind = kind
+        self.D = D; self.N = N; self.P = P; self.use_ln = use_ln; self.clip = float(clip)
+        self.ndir = ndir; self.I = I; self.F = F; self.npu = npu; self.npl = npl
+        self.stateful = stateful; self.context = context
+        self.out_dim = ndir * (P if P else N)
+        self.ln_kind = 2 if kind == 'icond_ln_prj' else (1 if (use_ln or kind == 'ln_prj') else 0)
+        self.cell_ln = 1 if (kind == 'ln_prj' or (kind in ('lstm', 'lhuc') and use_ln)) else 0
+        self.dirs = [_mk_lstm_family(net.store, 'L%d.%d.' % (idx, d), kind, D, N, P,
+                                     self.ln_kind == 1, I, F, npu, npl) for d in range(ndir)]
+        self.reverse = [False, True][:ndir]
+        self.state = [None] * ndir           # TBPTT (c, r) per direction
+
+    def describe(self):
+        out = {}
+        for d, nm in enumerate(('fwd', 'bwd')):
+            if d >= self.ndir:
+                out[nm] = None
+                continue
+            k = self.kind
+            if k in ('lstm', 'lhuc'):
+                args = dict(num_units=self.N, num_proj_units=self.P, use_layer_norm=self.use_ln,
+                            grad_clipping=self.clip, backwards=self.reverse[d])
+                if k == 'lstm':
+                    args.update(stateful=self.stateful and d == 0, context=self.context)
+                else:
+                    args.update(num_pred_units=self.npu, num_pred_layers=self.npl,
+                                stateful=self.stateful and d == 0, context=self.context)
+            elif k in ('prj', 'ln_prj'):
+                args = dict(num_units=self.N, num_factors=self.P, grad_clipping=self.clip,
+                            backwards=self.reverse[d])
+            else:
+                args = dict(num_units=self.N, num_factors=self.F, grad_clipping=self.clip,
+                            backwards=self.reverse[d])
+            out[nm] = dict(kind=k, args=args, params=[r[0] for r in self.dirs[d].refmap])
+        return out
+
+    # -- TBPTT state (libs/lhuclstm_layers.py:221-228)
+    def reset(self, batch_size):
+        dev = self.net.device
+        self.state = [(torch.zeros(batch_size, self.N, device=dev), torch.zeros(batch_size, self.N, device=dev))
+                      if (self.stateful and d == 0) else None for d in range(self.ndir)]
+
+    def _buf(self, name, rows, cols, zero=False):
+        return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols, zero)
+
+    def forward(self, X, T, B, mask, cond, train):
+        net = self.net; N = self.N; P = self.P; rows = T * B
+        Pout = P if P else N
+        Y = self._buf('Y', rows, self.out_dim)
+        desc = _lib.LstmScanDesc()
+        desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
+        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, cond=cond, Y=Y, d=[])
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            xin = self._buf('xin%d' % d, rows, 4 * N)
+            if self.kind == 'icond_ln_prj':
+                Tc = cond.shape[1]
+                pre = self._buf('pre%d' % d, B * Tc, self.F)
+                ops.gemm(cond.view(B * Tc, self.I), dp.p('Wc'), pre)
+                ops.bias_act(pre, dp.p('bc'), B * Tc, self.F, 2)
+                s = self._buf('s%d' % d, B, self.F)
+                ops.masked_mean(pre, mask, B, Tc, self.F, s)
+                al_in = self._buf('al_in%d' % d, B, 4 * N); al_hid = self._buf('al_hid%d' % d, B, 4 * N)
+                bt = self._buf('bt%d' % d, B, 4 * N)
+                ops.gemm(s, dp.p('Wai'), al_in, bias=dp.p('bai'))
+                ops.gemm(s, dp.p('Wah'), al_hid, bias=dp.p('bah'))
+                ops.gemm(s, dp.p('Wbt'), bt, bias=dp.p('bbt'))
+                c.update(pre=pre, s=s, al_in=al_in, al_hid=al_hid, bt=bt)
+            if self.ln_kind == 0:
+                ops.gemm(X, dp.p('Wx'), xin, bias=dp.p('b'))
+            else:
+                ops.gemm(X, dp.p('Wx'), xin)
+                xh = self._buf('xhat_in%d' % d, rows, 4 * N); rs = self._buf('rs_in%d' % d, rows, 1)
+                if self.ln_kind == 1:
+                    ops.ln_rows_fwd(xin, 4 * N, dp.p('a_in'), xin, beta=dp.p('b_in') if dp.has('b_in') else None,
+                                    bias=dp.p('b'), xhat=xh, rstd=rs)
+                else:
+                    ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, pre=c['bt'], pmod=B, amod=B, xhat=xh, rstd=rs)
+                c.update(xhat_in=xh, rs_in=rs)
+            if P:
+                Wf = self._buf('Wf%d' % d, N, 4 * N)
+                ops.gemm(dp.p('Wp'), dp.p('Wh'), Wf)
+            else:
+                Wf = dp.p('Wh')
+            c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d),
+                                                             _lib.lib().asr_lstm_pack_floats(N, 0)))
+            if train:
+                c['wpkb'] = ops.lstm_pack(Wf, N, 1, net.arena.get('L%d.wpkb%d' % (self.idx, d),
+                                                                  _lib.lib().asr_lstm_pack_floats(N, 1)))
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            Dd.xin = xin.data_ptr(); Dd.wpack = c['wpk'].data_ptr()
+            if self.ln_kind == 1:
+                Dd.alpha_hid = dp.p('a_hid').data_ptr()
+                Dd.beta_hid = dp.p('b_hid').data_ptr() if dp.has('b_hid') else None
+            elif self.ln_kind == 2:
+                Dd.alpha_hid = c['al_hid'].data_ptr()
+            if self.cell_ln:
+                Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
+            st = self.state[d]
+            if st is not None:
+                c['c0'] = st[0].clone(); c['r0'] = st[1].clone()
+                Dd.c0 = c['c0'].data_ptr(); Dd.r0 = c['r0'].data_ptr()
+            direct = (not P) and self.kind != 'lhuc'       # scan writes straight into Y's column block
+            if direct:
+                R = Y[:, d * N:(d + 1) * N]
+            else:
+                R = self._buf('R%d' % d, rows, N)
+            c['R'] = R
+            Dd.r_out = R.data_ptr(); Dd.ld_r = R.stride(0)
+            c['cst'] = self._buf('cst%d' % d, rows, N); Dd.cst = c['cst'].data_ptr()
+            if train:
+                c['gates'] = self._buf('gates%d' % d, rows, 4 * N); Dd.gates = c['gates'].data_ptr()
+            if self.ln_kind:
+                c['ahat'] = self._buf('ahat%d' % d, rows, 4 * N); c['rs_a'] = self._buf('rs_a%d' % d, rows, 1)
+                Dd.ahat = c['ahat'].data_ptr(); Dd.rs_a = c['rs_a'].data_ptr()
+            if self.cell_ln:
+                c['chat'] = self._buf('chat%d' % d, rows, N); c['rs_c'] = self._buf('rs_c%d' % d, rows, 1)
+                Dd.chat = c['chat'].data_ptr(); Dd.rs_c = c['rs_c'].data_ptr()
+            ctx['d'].append(c)
+        net.scan_lstm(self, desc, backward=False)
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            if self.stateful and self.state[d] is not None:     # libs/lhuclstm_layers.py:313-319
+                last = T - 1
+                if self.context:
+                    last = (T if T < self.context else self.context) - 1
+                self.state[d] = (c['cst'][last * B:(last + 1) * B].clone(),
+                                 c['R'][last * B:(last + 1) * B].clone())
+            Yd = Y[:, d * Pout:(d + 1) * Pout]
+            if P and self.kind != 'lhuc':
+                ops.gemm(c['R'], dp.p('Wp'), Yd)
+            elif self.kind == 'lhuc':
+                if P:
+                    hid = self._buf('hid%d' % d, rows, P)
+                    ops.gemm(c['R'], dp.p('Wp'), hid)
+                else:
+                    hid = c['R']
+                c['hid'] = hid
+                emb = cond[:, 0, :].contiguous()            # libs/lhuclstm_layers.py:504-510
+                acts = [emb]
+                for i in range(self.npl):
+                    a = self._buf('lh_a%d_%d' % (i, d), B, self.npu)
+                    ops.gemm(acts[-1], dp.p('We%d' % i), a)
+                    ops.bias_act(a, dp.p('be%d' % i), B, self.npu, 1)
+                    acts.append(a)
+                sf = self._buf('lh_sf%d' % d, B, Pout)
+                ops.gemm(acts[-1], dp.p('We%d' % self.npl), sf, bias=dp.p('be%d' % self.npl))
+                c['acts'] = acts; c['sf'] = sf
+                ops.rowscale(hid, hid.stride(0), sf, B, True, Yd, Yd.stride(0), rows, Pout)
+        return Y
+
+    def backward(self, dY, need_dx=True):
+        net = self.net; ctx = self.ctx; N = self.N; P = self.P
+        X, T, B, mask, cond = ctx['X'], ctx['T'], ctx['B'], ctx['mask'], ctx['cond']
+        rows = T * B
+        Pout = P if P else N
+        desc = _lib.LstmScanDesc()
+        desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
+        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            dYd = dY[:, d * Pout:(d + 1) * Pout]
+            if self.kind == 'lhuc':
+                sf = c['sf']; hid = c['hid']; acts = c['acts']
+                dsf = self._buf('lh_dsf%d' % d, B, Pout)
+                ops.colreduce(dYd, dsf, rows, Pout, y=hid, gmod=B, ldx=dYd.stride(0), ldy=hid.stride(0))
+                ops.act_bwd(dsf, sf, B, Pout, 1)              # relu'(sf)
+                dhid = self._buf('lh_dhid%d' % d, rows, Pout)
+                ops.rowscale(dYd, dYd.stride(0), sf, B, True, dhid, Pout, rows, Pout)
+                ops.gemm(acts[-1], dsf, dp.g('We%d' % self.npl), ta=True)
+                ops.colreduce(dsf, dp.g('be%d' % self.npl), B, Pout)
+                da = dsf
+                for i in range(self.npl - 1, -1, -1):
+                    dprev = self._buf('lh_da%d_%d' % (i, d), B, self.npu)
+                    ops.gemm(da, dp.p('We%d' % (i + 1)), dprev, tb=True)
+                    ops.act_bwd(dprev, acts[i + 1], B, self.npu, 1)
+                    ops.gemm(acts[i], dprev, dp.g('We%d' % i), ta=True)
+                    ops.colreduce(dprev, dp.g('be%d' % i), B, self.npu)
+                    da = dprev
+                dYd = dhid
+            if P:
+                dR = self._buf('dR%d' % d, rows, N)
+                ops.gemm(dYd, dp.p('Wp'), dR, tb=True)
+                ops.gemm(c['R'], dYd, dp.g('Wp'), ta=True)
+            else:
+                dR = dYd
+            c['dR'] = dR
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            Dd.wpack = c['wpkb'].data_ptr()
+            if self.ln_kind == 1:
+                Dd.alpha_hid = dp.p('a_hid').data_ptr()
+            elif self.ln_kind == 2:
+                Dd.alpha_hid = c['al_hid'].data_ptr()
+            if self.cell_ln:
+                Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
+            if 'c0' in c:
+                Dd.c0 = c['c0'].data_ptr(); Dd.r0 = c['r0'].data_ptr()
+            Dd.gates = c['gates'].data_ptr(); Dd.cst = c['cst'].data_ptr()
+            if self.ln_kind:
+                Dd.ahat = c['ahat'].data_ptr(); Dd.rs_a = c['rs_a'].data_ptr()
+                c['dA'] = self._buf('dA%d' % d, rows, 4 * N); Dd.dA = c['dA'].data_ptr()
+            if self.cell_ln:
+                Dd.chat = c['chat'].data_ptr(); Dd.rs_c = c['rs_c'].data_ptr()
+                c['dOut'] = self._buf('dOut%d' % d, rows, N); Dd.dOut = c['dOut'].data_ptr()
+            Dd.dr_ext = dR.data_ptr(); Dd.ld_dr = dR.stride(0)
+            c['dG'] = self._buf('dG%d' % d, rows, 4 * N); Dd.dG = c['dG'].data_ptr()
+        net.scan_lstm(self, desc, backward=True)
+        dX = self._buf('dX', rows, self.D) if need_dx else None
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            dG = c['dG']; dA = c['dA'] if self.ln_kind else dG
+            R = c['R']
+            # dW' = sum_t r_{prev(t)}^T dA_t
+            dWf = self._buf('dWf%d' % d, N, 4 * N) if P else dp.g('Wh')
+            n1 = (T - 1) * B
+            if not self.reverse[d]:
+                Ra, dAb, first = R[:n1], dA[B:], dA[:B]
+            else:
+                Ra, dAb, first = R[B:], dA[:n1], dA[n1:]
+            ops.gemm(Ra, dAb, dWf, ta=True)
+            if 'r0' in c:
+                ops.gemm(c['r0'], first, dWf, ta=True, beta=1.0)
+            if P:
+                ops.gemm(dp.p('Wp'), dWf, dp.g('Wh'), ta=True)
+                ops.gemm(dWf, dp.p('Wh'), dp.g('Wp'), tb=True, beta=1.0)
+            if dp.has('b'):
+                ops.colreduce(dG, dp.g('b'), rows, 4 * N)
+            if self.cell_ln:
+                ops.colreduce(c['dOut'], dp.g('a_c'), rows, N, y=c['chat'])
+                ops.colreduce(c['dOut'], dp.g('b_c'), rows, N)
+            if self.ln_kind == 0:
+                dXp = dG
+            else:
+                dXp = self._buf('dXp%d' % d, rows, 4 * N)
+                if self.ln_kind == 1:
+                    ops.colreduce(dG, dp.g('a_in'), rows, 4 * N, y=c['xhat_in'])
+                    ops.colreduce(dG, dp.g('a_hid'), rows, 4 * N, y=c['ahat'])
+                    if dp.has('b_in'):
+                        ops.colreduce(dG, dp.g('b_in'), rows, 4 * N)
+                        ops.colreduce(dG, dp.g('b_hid'), rows, 4 * N)
+                    ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], dp.p('a_in'), dXp)
+                else:
+                    F = self.F; Tc = cond.shape[1]
+                    dal_in = self._buf('dal_in%d' % d, B, 4 * N); dal_hid = self._buf('dal_hid%d' % d, B, 4 * N)
+                    dbt = self._buf('dbt%d' % d, B, 4 * N)
+                    ops.colreduce(dG, dal_in, rows, 4 * N, y=c['xhat_in'], gmod=B)
+                    ops.colreduce(dG, dal_hid, rows, 4 * N, y=c['ahat'], gmod=B)
+                    ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], c['al_in'], dXp, amod=B)
+                    ops.colreduce(dXp, dbt, rows, 4 * N, gmod=B)
+                    s = c['s']
+                    ds = self._buf('ds%d' % d, B, F)
+                    for k, (nm, dv) in enumerate((('ai', dal_in), ('ah', dal_hid), ('bt', dbt))):
+                        ops.gemm(s, dv, dp.g('W' + nm), ta=True)
+                        ops.colreduce(dv, dp.g('b' + nm), B, 4 * N)
+                        ops.gemm(dv, dp.p('W' + nm), ds, tb=True, beta=0.0 if k == 0 else 1.0)
+                    dpre = self._buf('dpre%d' % d, B * Tc, F)
+                    ops.masked_mean_tanh_bwd(ds, mask, c['pre'], B, Tc, F, dpre)
+                    ops.gemm(cond.view(B * Tc, self.I), dpre, dp.g('Wc'), ta=True)
+                    ops.colreduce(dpre, dp.g('bc'), B * Tc, F)
+            ops.gemm(X, dXp, dp.g('Wx'), ta=True)
+            if need_dx:
+                ops.gemm(dXp, dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+        return dX
+
+
+def _init_tensor(rng, shape, init):
+    """Reference initialisers (lasagne.init) on the host with numpy: Orthogonal (gain 1, SVD of a
+    Gaussian), Constant, Normal(std), GlorotUniform."""
+    if init == 'orthogonal':
+        flat = (shape[0], int(np.prod(shape[1:])))
+        a = rng.standard_normal(flat)
+        u, _, v = np.linalg.svd(a, full_matrices=False)
+        q = u if u.shape == flat else v
+        return q.reshape(shape).astype(np.float32)
+    if init == 'glorot_uniform':
+        lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+        return rng.uniform(-lim, lim, shape).astype(np.float32)
+    kind, v = init
+    if kind == 'normal':
+        return (rng.standard_normal(shape) * v).astype(np.float32)
+    return np.full(shape, v, dtype=np.float32)
+
+
+class Network(object):
+    """The stacked model + output layer.  Built by asr_amd.builders / asr_amd.gating_hyper_nets."""
+    def __init__(self, device='cuda:0'):
+        self.device = torch.device(device)
+        self.store = ParamStore()
+        self.arena = Arena(self.device)
+        self.pairs = []
+        self.pair_specs = []       # per pair: list (per direction) of [(ref_name, shape, init)]
+        self.out = None
+        self.ivector_concat = False
+        self.uses_cond = False
+        self.output_mode = 'softmax'      # what ff_fn returns: 'softmax' probabilities or 'logits'
+        self._ws = {}
+        self.finalized = False
+
+    # ---- construction -------------------------------------------------------------------------
+    def add_pair(self, pair, spec_per_dir):
+        self.pairs.append(pair)
+        self.pair_specs.append(spec_per_dir)
+        return pair
+
+    def set_output(self, K, C_, mode):
+        self.out = DirParams(self.store, 'out.')
+        self.out.add('W', (K, C_)); self.out.add('b', (C_,))
+        self.out.map('W', 'W'); self.out.map('b', 'b')
+        self.out_spec = specs.dense_params(K, C_)
+        self.K_top = K; self.C = C_
+        self.output_mode = mode
+
+    def finalize(self, seed=0):
+        self.store.materialize(self.device)
+        rng = np.random.default_rng(seed)
+        for pair, sp in zip(self.pairs, self.pair_specs):
+            for dp, spec in zip(pair.dirs, sp):
+                vals = {n: torch.from_numpy(_init_tensor(rng, s, i)).to(self.device) for n, s, i in spec}
+                dp.load_ref(vals)
+        vals = {n: torch.from_numpy(_init_tensor(rng, s, i)).to(self.device) for n, s, i in self.out_spec}
+        self.out.load_ref(vals)
+        self.m = torch.zeros_like(self.store.p)
+        self.v = torch.zeros_like(self.store.p)
+        self.t_prev = 0
+        self.scal = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self.adam_ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
+        self.finalized = True
+        return self
+
+    # ---- reference-compatible parameter lists -------------------------------------------------
+    def _all_dirparams(self):
+        out = []
+        for pair in self.pairs:
+            out.extend(pair.dirs)
+        out.append(self.out)
+        return out
+
+    def param_names_shapes(self):
+        res = []
+        for dp in self._all_dirparams():
+            for ref_name, name, kind, arg in dp.refmap:
+                E = dp.p(name)
+                v = _PermView(E).to_ref() if kind == 'perm4' else dp._view(E, kind, arg)
+                res.append((ref_name, tuple(v.shape)))
+        return res
+
+    def get_all_param_values(self, grads=False):
+        """= lasagne.layers.get_all_param_values(network, trainable=True): list of numpy arrays in
+        the reference's order (libs/utils.py:80-85 pickles exactly this list)."""
+        return [v for dp in self._all_dirparams() for _, v in dp.dump_ref(grads)]
+
+    def get_all_grad_values(self):
+        return self.get_all_param_values(grads=True)
+
+    def set_all_param_values(self, values):
+        """libs/lasagne_libs/utils.py:2-14: same count / shape checks, same ValueError text."""
+        ns = self.param_names_shapes()
+        if len(ns) != len(values):
+            raise ValueError("mismatch: got %d values to set %d parameters" % (len(values), len(ns)))
+        for (n, shp), v in zip(ns, values):
+            if tuple(np.shape(v)) != shp:
+                raise ValueError("mismatch: parameter has shape %r but value to set has shape %r"
+                                 % (shp, tuple(np.shape(v))))
+        k = 0
+        for dp in self._all_dirparams():
+            vals = {}
+            for ref_name, _, _, _ in dp.refmap:
+                vals[ref_name] = torch.from_numpy(np.ascontiguousarray(values[k], dtype=np.float32)).to(self.device)
+                k += 1
+            dp.load_ref(vals)
+
+    def describe(self):
+        """Plain-data description of the wiring (consumed by the test oracle)."""
+        layers = []
+        for pair in self.pairs:
+            layers.append(pair.describe())
+        return dict(layers=layers, output=self.output_mode, ivector_concat=self.ivector_concat,
+                    cond=self.uses_cond)
+
+    def tbptt_layers(self):
+        return [p for p in self.pairs if getattr(p, 'stateful', False)]
+
+    # ---- scan launch helpers ------------------------------------------------------------------
+    def _workspace(self, key, nbytes):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def scan_lstm(self, pair, desc, backward):
+        L = _lib.lib()
+        need = L.asr_lstm_scan_ws_bytes(desc.T, desc.B, desc.N, desc.ndir, int(backward))
+        ws = self._workspace(('lstm', pair.idx, backward), need)
+        fn = L.asr_lstm_scan_bwd if backward else L.asr_lstm_scan_fwd
+        check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+              'asr_lstm_scan_%s' % ('bwd' if backward else 'fwd'))
+        self._last_groups = getattr(self, '_last_groups', {})
+        self._last_groups[('lstm', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
+
+    def check_status(self):
+        """Call after a host sync: raises if any persistent scan gave up on a bounded wait."""
+        torch.cuda.synchronize(self.device)
+        for key, ng in getattr(self, '_last_groups', {}).items():
+            check(_lib.lib().asr_scan_status(self._ws[key].data_ptr(), ng), 'persistent scan %r' % (key,))
+
+    # ---- forward / loss / backward ------------------------------------------------------------
+    def _prep_input(self, x, cond):
+        B, T, D = x.shape
+        Din = D + (cond.shape[2] if self.ivector_concat else 0)
+        X0 = self.arena.mat('X0', T * B, Din)
+        ops.swap01(x, X0, B, T, D, D, Din)
+        if self.ivector_concat:                      # libs/deep_lstm_builder.py:14-16
+            I = cond.shape[2]
+            ops.swap01(cond, X0[:, D:], B, T, I, I, Din)
+        return X0
+
+    def forward(self, x, mask, cond=None, train=False):
+        """x (B,T,D) float32 cuda, mask (B,T) float32, cond (B,T,I).  Returns time-major logits
+        (T*B, C)."""
+        assert self.finalized
+        B, T, D = x.shape
+        x = x.contiguous(); mask = mask.contiguous()
+        if cond is not None:
+            cond = cond.contiguous()
+        self.B, self.T = B, T
+        act = self._prep_input(x, cond)
+        for pair in self.pairs:
+            act = pair.forward(act, T, B, mask, cond, train)
+        self.top = act
+        logits = self.arena.mat('logits', T * B, self.C)
+        ops.gemm(act, self.out.p('W'), logits, bias=self.out.p('b'))   # libs/builder_utils.py:44-45
+        self.logits = logits
+        return logits
+
+    def posteriors(self, x, mask, cond=None, log=False):
+        """ff_fn body (libs/comp_graph_utils.py:321-333): (B,T,C) probabilities, or the raw logits for
+        gating_hyper_nets models; log=True gives the max-subtracted log-softmax of
+        bin/forward_ln_lstmp.py:55-58."""
+        logits = self.forward(x, mask, cond, train=False)
+        B, T = self.B, self.T
+        out = torch.empty(B, T, self.C, dtype=torch.float32, device=self.device)
+        if self.output_mode == 'logits' and not log:
+            ops.swap01(logits, out, T, B, self.C)
+        else:
+            ops.softmax_ce(logits, self.C, B, T, out_mode=1 if log else 2, out=out)
+        return out
+
+    def loss(self, x, mask, target, target_mask, cond=None, train=True, context=0):
+        """compute_loss (libs/comp_graph_utils.py:29-45) / compute_loss_tbptt (:47-66, context form).
+        Leaves dlogits (scaled by 1/n_batch, libs/comp_graph_utils.py:40) ready for backward()."""
+        logits = self.forward(x, mask, cond, train=train)
+        B, T = self.B, self.T
+        rows = T * B
+        tm = target_mask.contiguous()
+        if context and context < T:
+            tm = tm.clone(); tm[:, context:] = 0
+        target = target.contiguous()
+        dl = self.arena.mat('dlogits', rows, self.C) if train else None
+        row_ce = self.arena.get('row_ce', rows); row_ok = self.arena.get('row_ok', rows)
+        pred = torch.empty(B, T, dtype=torch.int32, device=self.device)
+        ops.softmax_ce(logits, self.C, B, T, target=target, tmask=tm, scale=1.0 / B, dlogits=dl,
+                       row_ce=row_ce, row_ok=row_ok, pred=pred)
+        ops.reduce_sum(row_ce, rows, self.scal[0:1])
+        ops.reduce_sum(row_ok, rows, self.scal[1:2])
+        self.dlogits = dl
+        if context and context < T:
+            pred = pred[:, :context]
+        return self.scal[0:1], self.scal[1:2], pred
+
+    def backward(self):
+        """theano.grad(ce_cost, params) (libs/comp_graph_utils.py:73-75) into the flat grad buffer."""
+        dl = self.dlogits
+        ops.gemm(self.top, dl, self.out.g('W'), ta=True)
+        ops.colreduce(dl, self.out.g('b'), dl.shape[0], self.C)
+        dY = self.arena.mat('dtop', dl.shape[0], self.K_top)
+        ops.gemm(dl, self.out.p('W'), dY, tb=True)
+        for i in range(len(self.pairs) - 1, -1, -1):
+            dY = self.pairs[i].backward(dY, need_dx=(i > 0))
+
+    def adam_update(self, lr, b1=0.9, b2=0.999, eps=1e-8, want_sqrt=True):
+        """libs/lasagne_libs/updates.py:587-617 on the flat buffer + grads_norm
+        (libs/comp_graph_utils.py:77; TBPTT trainer returns the un-rooted sum, :111)."""
+        self.t_prev += 1
+        t = self.t_prev
+        a_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        ops.adam_step(self.store.p, self.store.g, self.m, self.v, float(a_t), b1, b2, eps,
+                      self.scal[2:3], want_sqrt, self.adam_ws)
+        return self.scal[2:3]
+
+    def grads_norm(self, want_sqrt=True):
+        ops.sqsum(self.store.g, self.scal[2:3], want_sqrt, self.adam_ws)
+        return self.scal[2:3]

@@ -1,0 +1,125 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/asr_amd.h).  torch is used for device memory
+and streams only; every arithmetic op below is a HIP kernel in libasr_amd.so."""
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk2d(t):
+    assert t.dim() == 2 and (t.numel() == 0 or t.stride(1) == 1) and t.dtype == torch.float32, \
+        (t.shape, t.stride(), t.dtype)
+
+
+def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
+    """Cm = alpha*op(A)*op(B) + beta*Cm (+bias).  2-D float32 views with unit inner stride."""
+    _chk2d(A); _chk2d(B); _chk2d(Cm)
+    M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if tb else (B.shape[0], B.shape[1])
+    assert K == K2 and tuple(Cm.shape) == (M, N), (A.shape, B.shape, Cm.shape, ta, tb)
+    check(_lib.lib().asr_gemm_f32(int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B),
+                                  max(B.stride(0), 1), beta, _p(Cm), max(Cm.stride(0), 1), _p(bias), _s()),
+          'asr_gemm_f32')
+    return Cm
+
+
+def swap01(src, dst, A, B, D, ld_src=None, ld_dst=None):
+    check(_lib.lib().asr_swap01(_p(src), _p(dst), A, B, D, ld_src or D, ld_dst or D, _s()), 'asr_swap01')
+    return dst
+
+
+def ln_rows_fwd(x, n, alpha, y, pre=None, pmod=1, beta=None, amod=0, bias=None, xhat=None, rstd=None):
+    rows = x.numel() // n
+    check(_lib.lib().asr_ln_rows_fwd(_p(x), rows, n, _p(pre), pmod, _p(alpha), _p(beta), amod, _p(bias),
+                                     _p(y), _p(xhat), _p(rstd), _s()), 'asr_ln_rows_fwd')
+    return y
+
+
+def ln_rows_bwd(dy, n, xhat, rstd, alpha, dx, amod=0):
+    rows = dy.numel() // n
+    check(_lib.lib().asr_ln_rows_bwd(_p(dy), rows, n, _p(xhat), _p(rstd), _p(alpha), amod, _p(dx), _s()),
+          'asr_ln_rows_bwd')
+    return dx
+
+
+_cr_ws = {}
+
+
+def colreduce(x, out, rows, n, y=None, gmod=1, accumulate=False, ldx=None, ldy=None):
+    """out[g,c] (+)= sum_{r % gmod == g} x[r,c] * (y[r,c] if y is given)."""
+    L = _lib.lib()
+    need = L.asr_colreduce_ws_bytes(n, gmod)
+    key = (x.device, )
+    ws = _cr_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(need // 4 + 16, dtype=torch.float32, device=x.device)
+        _cr_ws[key] = ws
+    check(L.asr_colreduce(_p(x), ldx or n, _p(y), ldy or n, rows, n, gmod, _p(out), int(accumulate),
+                          _p(ws), ws.numel() * 4, _s()), 'asr_colreduce')
+    return out
+
+
+def bias_act(x, bias, rows, n, act):
+    check(_lib.lib().asr_bias_act(_p(x), _p(bias), rows, n, act, _s()), 'asr_bias_act')
+    return x
+
+
+def act_bwd(dy, y, rows, n, act):
+    check(_lib.lib().asr_act_bwd(_p(dy), _p(y), rows, n, act, _s()), 'asr_act_bwd')
+    return dy
+
+
+def rowscale(x, ldx, s, B, relu, y, ldy, rows, n):
+    check(_lib.lib().asr_rowscale(_p(x), ldx, _p(s), B, int(relu), _p(y), ldy, rows, n, _s()),
+          'asr_rowscale')
+    return y
+
+
+def masked_mean(x, mask, B, T, F, out):
+    check(_lib.lib().asr_masked_mean(_p(x), _p(mask), B, T, F, _p(out), _s()), 'asr_masked_mean')
+    return out
+
+
+def masked_mean_tanh_bwd(ds, mask, pre, B, T, F, dpre):
+    check(_lib.lib().asr_masked_mean_tanh_bwd(_p(ds), _p(mask), _p(pre), B, T, F, _p(dpre), _s()),
+          'asr_masked_mean_tanh_bwd')
+    return dpre
+
+
+def softmax_ce(logits, C_, B, T, target=None, tmask=None, scale=0.0, dlogits=None, row_ce=None,
+               row_ok=None, pred=None, out_mode=0, out=None):
+    """target/tmask are the caller's batch-major (B,T) arrays (strides taken from the tensors)."""
+    tsb, tst = (target.stride(0), target.stride(1)) if target is not None else (0, 0)
+    msb, mst = (tmask.stride(0), tmask.stride(1)) if tmask is not None else (0, 0)
+    check(_lib.lib().asr_softmax_ce(_p(logits), C_, B, T, _p(target), tsb, tst, _p(tmask), msb, mst,
+                                    scale, _p(dlogits), _p(row_ce), _p(row_ok), _p(pred), out_mode,
+                                    _p(out), _s()), 'asr_softmax_ce')
+
+
+def reduce_sum(x, n, out, do_sqrt=False):
+    check(_lib.lib().asr_reduce_sum(_p(x), n, _p(out), int(do_sqrt), _s()), 'asr_reduce_sum')
+    return out
+
+
+def adam_step(p, g, m, v, a_t, b1, b2, eps, norm_out, want_sqrt, ws):
+    check(_lib.lib().asr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), a_t, b1, b2, eps, _p(norm_out),
+                                   int(want_sqrt), _p(ws), _s()), 'asr_adam_step')
+
+
+def sqsum(g, out, want_sqrt, ws):
+    check(_lib.lib().asr_sqsum(_p(g), g.numel(), _p(out), int(want_sqrt), _p(ws), _s()), 'asr_sqsum')
+
+
+def lstm_pack(W, N, mode, out):
+    assert W.is_contiguous() and out.numel() >= _lib.lib().asr_lstm_pack_floats(N, mode)
+    check(_lib.lib().asr_lstm_pack_w(_p(W), N, mode, _p(out), _s()), 'asr_lstm_pack_w')
+    return out

@@ -1,0 +1,128 @@
+/* asr_amd C-ABI  --  MI355X (gfx950) kernels for the acoustic-model hot path of gunkisu/asr.
+ *
+ * The reference has NO native/FFI interface for this path: all arithmetic goes through Theano ops
+ * (T.dot / theano.scan / theano.grad) called from Python layer classes, so every entry point below
+ * cites the reference Python it replaces (paths relative to the reference root).  The boundary a
+ * reference maintainer binds is Python -> ctypes.
+ *
+ * Conventions: all pointers are DEVICE pointers owned by the caller; all tensors float32, row-major;
+ * sequences are time-major (T,B,...) with rows r = t*B + b;  "4N" gate vectors are stored in the
+ * engine's gate-interleaved column order  col = unit*4 + gate  (gate order ingate, forgetgate,
+ * cell, outgate: libs/lhuclstm_layers.py:58-60).  Every function takes the HIP stream to enqueue on,
+ * returns 0 or a negative ASR_ERR_* code, never throws, never allocates (workspaces are sized by the
+ * *_ws_bytes helpers and passed in).  Thread-compatible: concurrent calls must use different
+ * workspaces; two persistent scans must never run concurrently on one device.
+ */
+#ifndef ASR_AMD_H
+#define ASR_AMD_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* asr_stream_t; /* hipStream_t */
+
+#define ASR_OK 0
+#define ASR_ERR_ARG (-1)
+#define ASR_ERR_LAUNCH (-2)
+#define ASR_ERR_WS (-3)
+#define ASR_ERR_TIMEOUT (-4)
+
+/* K1.  C = alpha*op(A)*op(B) + beta*C (+bias[N] per row); exact-fp32 MFMA.  Replaces every T.dot on
+ * the path: input projection libs/lhuclstm_layers.py:189, libs/lasagne_libs/recurrent_layers.py:701,
+ * :1233, libs/lasagne_libs/hyper_lhuc_layers.py:469; output layer libs/builder_utils.py:44-45;
+ * and the dX / dW contractions theano.grad derives from them (libs/comp_graph_utils.py:74). */
+int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                 const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                 asr_stream_t stream);
+
+/* dst[b][a][:] = src[a][b][:]  -- input.dimshuffle(1,0,2), libs/lhuclstm_layers.py:181,213 */
+int asr_swap01(const float* src, float* dst, int A, int B, int D, int ld_src, int ld_dst,
+               asr_stream_t stream);
+
+/* Row layer norm hoisted out of the recurrence: ln()/sample_ln() of the input-side pre-activation,
+ * libs/lhuclstm_layers.py:16-21,77; libs/lasagne_libs/recurrent_layers.py:10-15,27-32,711,1241. */
+int asr_ln_rows_fwd(const float* x, int rows, int n, const float* pre, int pmod, const float* alpha,
+                    const float* beta, int amod, const float* bias, float* y, float* xhat, float* rstd,
+                    asr_stream_t stream);
+int asr_ln_rows_bwd(const float* dy, int rows, int n, const float* xhat, const float* rstd,
+                    const float* alpha, int amod, float* dx, asr_stream_t stream);
+
+/* Deterministic column reductions = the gradients theano.grad produces for b / alpha / beta vectors. */
+size_t asr_colreduce_ws_bytes(int n, int gmod);
+int asr_colreduce(const float* x, int ldx, const float* y, int ldy, int rows, int n, int gmod,
+                  float* out, int accumulate, float* ws, size_t ws_bytes, asr_stream_t stream);
+
+/* small MLP pieces: LHUC predictor libs/lhuclstm_layers.py:402-409, conditioning prologue
+ * libs/lasagne_libs/recurrent_layers.py:1209-1211.  act: 0 identity, 1 relu, 2 tanh */
+int asr_bias_act(float* x, const float* bias, int rows, int n, int act, asr_stream_t stream);
+int asr_act_bwd(float* dy, const float* y, int rows, int n, int act, asr_stream_t stream);
+int asr_rowscale(const float* x, int ldx, const float* s, int B, int relu, float* y, int ldy, int rows,
+                 int n, asr_stream_t stream);                 /* LHUC, libs/lhuclstm_layers.py:461-462 */
+int asr_masked_mean(const float* x, const float* mask, int B, int T, int F, float* out,
+                    asr_stream_t stream);
+int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, const float* pre, int B, int T, int F,
+                             float* dpre, asr_stream_t stream);
+
+/* K3.  Fused log-softmax / CE / argmax / dlogits: libs/comp_graph_utils.py:29-45,
+ * scripts/hypernets/exp_prj_ln_lstm_fix.py:84-95, bin/forward_ln_lstmp.py:55-58.
+ * out_mode 0 none, 1 log-posteriors, 2 probabilities, written batch-major (B,T,C). */
+int asr_softmax_ce(const float* logits, int C, int B, int T, const int* target, int tgt_sb, int tgt_st,
+                   const float* tmask, int msk_sb, int msk_st, float scale, float* dlogits,
+                   float* row_ce, float* row_ok, int* pred, int out_mode, float* out,
+                   asr_stream_t stream);
+int asr_reduce_sum(const float* x, size_t n, float* out, int do_sqrt, asr_stream_t stream);
+
+/* K4.  Adam + gradient norm: libs/lasagne_libs/updates.py:587-617, libs/comp_graph_utils.py:77.
+ * ws: 1024 floats. */
+int asr_adam_step(float* p, const float* g, float* m, float* v, size_t n, float a_t, float b1, float b2,
+                  float eps, float* grads_norm_out, int want_sqrt, float* ws, asr_stream_t stream);
+int asr_sqsum(const float* g, size_t n, float* out, int want_sqrt, float* ws, asr_stream_t stream);
+
+/* K2 (LSTM family).  Persistent recurrent scan, forward and BPTT: theano.scan(step_masked) and its
+ * gradient for libs/lhuclstm_layers.py:73-130,205-211; libs/lasagne_libs/recurrent_layers.py:437-521,
+ * :707-789, :1237-1310. */
+typedef struct asr_lstm_dir {
+    int reverse;              /* go_backwards */
+    const float* xin;         /* (T,B,4N) input-side pre-activation incl. bias / input LN */
+    const float* wpack;       /* asr_lstm_pack_w output (mode 0 for fwd, 1 for bwd) */
+    const float* alpha_hid;   /* (4N) or (B,4N) for ln_kind 2 */
+    const float* beta_hid;    /* (4N) or NULL */
+    const float* alpha_c;     /* (N) */
+    const float* beta_c;      /* (N) */
+    const float* c0;          /* (B,N) initial cell or NULL (zeros) */
+    const float* r0;          /* (B,N) initial r    or NULL (zeros) */
+    float* r_out;             /* (T,B,ld_r) */
+    int ld_r;
+    float* gates;             /* (T,B,4N) saved for BPTT (NULL = inference) */
+    float* cst;               /* (T,B,N) */
+    float* ahat;              /* (T,B,4N)  LN */
+    float* rs_a;              /* (T,B)     LN */
+    float* chat;              /* (T,B,N)   cell LN */
+    float* rs_c;              /* (T,B)     cell LN */
+    const float* dr_ext;      /* (T,B,ld_dr) backward: dLoss/dr_t from above */
+    int ld_dr;
+    float* dG;                /* (T,B,4N) */
+    float* dA;                /* (T,B,4N) LN only */
+    float* dOut;              /* (T,B,N)  cell LN only */
+} asr_lstm_dir;
+
+typedef struct asr_lstm_scan_desc {
+    int T, B, N, ndir, ln_kind, cell_ln;   /* ln_kind: 0 none, 1 static, 2 per-sample alpha */
+    float grad_clip;                       /* theano.gradient.grad_clip bound, 0 = off */
+    const float* mask; int mask_stride_b, mask_stride_t;
+    asr_lstm_dir dir[2];
+} asr_lstm_scan_desc;
+
+size_t asr_lstm_pack_floats(int N, int mode);
+int asr_lstm_pack_w(const float* W, int N, int mode, float* out, asr_stream_t stream);
+size_t asr_lstm_scan_ws_bytes(int T, int B, int N, int ndir, int backward);
+int asr_lstm_scan_fwd(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+int asr_lstm_scan_bwd(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+/* after the stream is synchronised: ASR_ERR_TIMEOUT if any group's bounded wait expired */
+int asr_scan_status(const void* ws, int ngroups);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,81 @@
+"""Kernel-level GPU checks through the C-ABI: GEMM (all transposes, ragged sizes, strides, bias,
+accumulate), row layer norm, column reductions, softmax-CE, against float64 numpy."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(37, 123, 61), (256, 2048, 123), (1, 5, 3), (130, 129, 17), (64, 64, 0)])
+def test_gemm(ta, tb, M, N, K):
+    from asr_amd import ops
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N + 3)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    dA = torch.from_numpy(A).cuda(); dB = torch.from_numpy(B).cuda()
+    dC = torch.from_numpy(C0).cuda(); db = torch.from_numpy(bias).cuda()
+    ops.gemm(dA, dB, dC[:, :N], ta, tb, alpha=0.5, beta=1.0, bias=db)
+    torch.cuda.synchronize()
+    opA = A.T.astype(np.float64) if ta else A.astype(np.float64)
+    opB = B.T.astype(np.float64) if tb else B.astype(np.float64)
+    ref = 0.5 * (opA @ opB) + C0[:, :N] + bias
+    got = dC.cpu().numpy()
+    assert relerr(got[:, :N], ref) < 2e-6
+    assert (got[:, N:] == C0[:, N:]).all()          # the strided view's neighbours are untouched
+
+
+def test_ln_rows_and_colreduce():
+    from asr_amd import ops
+    rng = np.random.default_rng(1)
+    rows, n, B = 45, 72, 5
+    x = rng.standard_normal((rows, n)).astype(np.float32) * 2 + 0.5
+    al = rng.standard_normal((B, n)).astype(np.float32); pre = rng.standard_normal((B, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    dx = torch.from_numpy(x).cuda(); y = torch.empty_like(dx); xh = torch.empty_like(dx)
+    rs = torch.empty(rows, device='cuda')
+    ops.ln_rows_fwd(dx, n, torch.from_numpy(al).cuda(), y, pre=torch.from_numpy(pre).cuda(), pmod=B, amod=B,
+                    bias=torch.from_numpy(bias).cuda(), xhat=xh, rstd=rs)
+    ridx = np.arange(rows) % B
+    yo, (xho, so) = O.ln_fwd(x.astype(np.float64) + pre[ridx], al[ridx].astype(np.float64))
+    assert relerr(y.cpu().numpy(), yo + bias) < 1e-5
+    dy = rng.standard_normal((rows, n)).astype(np.float32)
+    ddx = torch.empty_like(dx)
+    ops.ln_rows_bwd(torch.from_numpy(dy).cuda(), n, xh, rs, torch.from_numpy(al).cuda(), ddx, amod=B)
+    dxo, dalo, _ = O.ln_bwd(dy.astype(np.float64), al[ridx].astype(np.float64), (xho, so))
+    assert relerr(ddx.cpu().numpy(), dxo) < 1e-5
+    out = torch.empty(B, n, device='cuda')
+    ops.colreduce(torch.from_numpy(dy).cuda(), out, rows, n, y=xh, gmod=B)
+    ref = np.zeros((B, n))
+    np.add.at(ref, ridx, dalo)
+    assert relerr(out.cpu().numpy(), ref) < 1e-5
+
+
+def test_softmax_ce_kernel():
+    from asr_amd import ops
+    rng = np.random.default_rng(2)
+    B, T, C = 4, 9, 3436
+    lg = (rng.standard_normal((T * B, C)) * 4).astype(np.float32)
+    y = rng.integers(0, C, (B, T)).astype(np.int32)
+    m = (rng.random((B, T)) > 0.3).astype(np.float32)
+    dl = torch.empty(T * B, C, device='cuda'); rce = torch.empty(T * B, device='cuda')
+    rok = torch.empty(T * B, device='cuda'); pred = torch.empty(B, T, dtype=torch.int32, device='cuda')
+    out = torch.empty(B, T, C, device='cuda')
+    ops.softmax_ce(torch.from_numpy(lg).cuda(), C, B, T, target=torch.from_numpy(y).cuda(),
+                   tmask=torch.from_numpy(m).cuda(), scale=1.0 / B, dlogits=dl, row_ce=rce, row_ok=rok,
+                   pred=pred, out_mode=1, out=out)
+    lgb = lg.reshape(T, B, C).transpose(1, 0, 2).astype(np.float64)
+    cost, s, p, dlo = O.softmax_ce(lgb, y, m.astype(np.float64))
+    assert abs(rce.sum().item() - s) / s < 1e-5
+    assert (pred.cpu().numpy() == p).all()
+    assert relerr(dl.cpu().numpy().reshape(T, B, C).transpose(1, 0, 2), dlo) < 1e-5
+    assert np.max(np.abs(out.cpu().numpy() - O.log_softmax(lgb))) < 2e-5

@@ -1,0 +1,188 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the float64 oracle on the same
+seeded inputs and weights -- posteriors, loss, argmax, every parameter gradient, Adam.
+Tolerance (BASELINE.json north_star): 1e-5 relative in fp32; we measure max|a-b| / max|b| per tensor
+and allow 2e-5 (fp32 accumulation over T dependent steps) for forward quantities and 1e-4 for
+gradients of the deepest nets (documented per test)."""
+import numpy as np
+import pytest
+import torch
+
+from common import make_batch, init_value
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return 'cuda:0'
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def perturb_params(net, seed, perturb=0.1, scale=1.0):
+    """Reference init + N(0, perturb) on every parameter (mandatory for the adaptive
+    paths, whose reference init is an exact identity)."""
+    rng = np.random.default_rng(seed)
+    vals = net.get_all_param_values()
+    new = [(v * scale + rng.standard_normal(v.shape) * perturb).astype(np.float32) for v in vals]
+    net.set_all_param_values(new)
+    return new
+
+
+def run_case(net, batch, cond_key=None, context=0, tol_f=2e-5, tol_g=1e-4, gscale=1.0):
+    dev = net.device
+    x = torch.from_numpy(batch['x']).to(dev); m = torch.from_numpy(batch['mask']).to(dev)
+    y = torch.from_numpy(batch['y']).to(dev)
+    cond = torch.from_numpy(batch[cond_key]).to(dev) if cond_key else None
+    vals = net.get_all_param_values()
+    onet = O.OracleNetwork(net.describe(), vals)
+    for l in onet.tbptt_layers():
+        l.reset(x.shape[0])
+    # forward posteriors
+    post = net.posteriors(x, m, cond).cpu().numpy()
+    net.check_status()
+    for l in net.tbptt_layers():
+        l.reset(x.shape[0])
+    opost = onet.posteriors(batch['x'], batch['mask'], batch.get(cond_key))
+    for l in onet.tbptt_layers():
+        l.reset(x.shape[0])
+    valid = batch['mask'][:, :, None] > 0
+    e = relerr(post * valid, opost * valid)
+    assert e < tol_f, ('posteriors', e)
+    # loss + grads
+    ce, ok, pred = net.loss(x, m, y, m, cond, train=True, context=context)
+    net.backward()
+    net.check_status()
+    oc, os_, opred, ograds = onet.loss_and_grads(batch['x'], batch['mask'], batch['y'], batch['mask'],
+                                                 batch.get(cond_key), context=context)
+    assert abs(ce.item() - os_) / abs(os_) < tol_f, (ce.item(), os_)
+    tm = batch['mask'] if not context else batch['mask'][:, :context]
+    assert ((pred.cpu().numpy() == opred) | (tm == 0)).all()
+    grads = net.get_all_grad_values()
+    names = [n for n, _ in net.param_names_shapes()]
+    worst = 0.0
+    gmax = max(np.max(np.abs(g)) for g in ograds)
+    for n, g, og in zip(names, grads, ograds):
+        assert g.shape == og.shape, (n, g.shape, og.shape)
+        err = float(np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax))
+        worst = max(worst, err)
+        assert err < tol_g, (n, err)
+    return e, worst
+
+
+SMALL = dict(B=3, T=7, D=5, C=6)
+
+
+@pytest.mark.parametrize('is_bidir', [False, True])
+@pytest.mark.parametrize('pj,use_ln', [(0, False), (4, False), (0, True), (4, True)])
+@pytest.mark.parametrize('clip', [0.0, 0.05])
+def test_build_deep_lstm_small(is_bidir, pj, use_ln, clip):
+    from asr_amd.builders import build_deep_lstm
+    net = build_deep_lstm(None, None, SMALL['D'], 2, 8, pj, SMALL['C'], clip, is_bidir, use_ln, 0,
+                          device=_dev(), seed=1)
+    perturb_params(net, 3, 0.15)
+    b = make_batch(np.random.default_rng(5), SMALL['B'], SMALL['T'], SMALL['D'], SMALL['C'])
+    run_case(net, b)
+
+
+def test_build_deep_lstm_ivector_input_medium():
+    """B=20 > 16 exercises the batch chunking; N=64 exercises multi-workgroup groups."""
+    from asr_amd.builders import build_deep_lstm
+    net = build_deep_lstm(None, None, 11, 2, 64, 0, 13, 1.0, True, False, 4, ivector_var=True,
+                          device=_dev(), seed=2)
+    perturb_params(net, 4, 0.02)
+    b = make_batch(np.random.default_rng(6), 20, 33, 11, 13, I=4)
+    run_case(net, b, cond_key='ivec')
+
+
+def test_ln_lstmp_model():
+    from asr_amd.gating_hyper_nets import deep_projection_ln_lstm_model
+    net = deep_projection_ln_lstm_model(None, None, 5, 6, 2, 4, 8, grad_clipping=0.05, dropout=0.0,
+                                        device=_dev(), seed=3)
+    perturb_params(net, 7, 0.15)
+    b = make_batch(np.random.default_rng(8), 3, 7, 5, 6)
+    run_case(net, b)
+
+
+def test_ln_lstmp_model_medium():
+    from asr_amd.gating_hyper_nets import deep_projection_ln_lstm_model
+    net = deep_projection_ln_lstm_model(None, None, 23, 17, 2, 32, 64, grad_clipping=1.0, dropout=0.0,
+                                        device=_dev(), seed=3)
+    perturb_params(net, 7, 0.03)
+    b = make_batch(np.random.default_rng(8), 16, 50, 23, 17)
+    run_case(net, b)
+
+
+def test_ivector_cond_ln_model():
+    from asr_amd.gating_hyper_nets import deep_projection_ivector_ln_model
+    net, cond_layers = deep_projection_ivector_ln_model(None, None, None, 5, 6, 2, 1, 3, 8,
+                                                        grad_clipping=0.05, dropout=0.0, cond_dim=3,
+                                                        device=_dev(), seed=4)
+    assert len(cond_layers) == 1
+    perturb_params(net, 9, 0.15)
+    b = make_batch(np.random.default_rng(10), 3, 7, 5, 6, I=3)
+    run_case(net, b, cond_key='ivec')
+
+
+def test_lhuc_ivector():
+    from asr_amd.builders import build_deep_lhuclstm_ivector
+    net, _ = build_deep_lhuclstm_ivector('ivector', None, None, 5, 2, 8, 0, 6, 1, 5, 0, 0, 0, 3, 0.05,
+                                         True, False, False, 3, True, device=_dev(), seed=5)
+    perturb_params(net, 11, 0.2)
+    b = make_batch(np.random.default_rng(12), 3, 7, 5, 6, I=3)
+    run_case(net, b, cond_key='ivec')
+
+
+def test_tbptt_windows_carry_state():
+    """3 windows incl. a last window shorter than the context (libs/lhuclstm_layers.py:313-319)."""
+    from asr_amd.builders import build_deep_lstm_tbptt
+    ctxt, rc = 3, 1
+    net, tb = build_deep_lstm_tbptt(None, None, 5, 2, 8, 0, 6, 3, ctxt, 0.05, False, False, 0,
+                                    device=_dev(), seed=6)
+    perturb_params(net, 13, 0.15)
+    b = make_batch(np.random.default_rng(14), 3, 8, 5, 6, lengths=[8, 1, 5])
+    vals = net.get_all_param_values()
+    onet = O.OracleNetwork(net.describe(), vals)
+    for l in tb:
+        l.reset(3)
+    for l in onet.tbptt_layers():
+        l.reset(3)
+    dev = net.device
+    full = (b['x'], b['mask'], b['x'], b['mask'], b['y'], b['mask'])
+    for win in O.gen_win(full, ctxt, rc):
+        xw, mw, _, _, yw, tmw = win
+        ce, ok, pred = net.loss(torch.from_numpy(np.ascontiguousarray(xw)).to(dev),
+                                torch.from_numpy(np.ascontiguousarray(mw)).to(dev),
+                                torch.from_numpy(np.ascontiguousarray(yw)).to(dev),
+                                torch.from_numpy(np.ascontiguousarray(tmw)).to(dev), None, True, ctxt)
+        net.backward()
+        net.check_status()
+        oc, os_, opred, ograds = onet.loss_and_grads(xw, mw, yw, tmw, None, context=ctxt)
+        assert abs(ce.item() - os_) <= 2e-5 * max(abs(os_), 1.0), (ce.item(), os_)
+        gmax = max(np.max(np.abs(g)) for g in ograds)
+        for g, og in zip(net.get_all_grad_values(), ograds):
+            assert np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax) < 1e-4
+
+
+def test_adam_step_matches_oracle():
+    from asr_amd.builders import build_deep_lstm
+    net = build_deep_lstm(None, None, 5, 1, 8, 0, 6, 0.0, False, False, 0, device=_dev(), seed=1)
+    b = make_batch(np.random.default_rng(5), 3, 7, 5, 6)
+    dev = net.device
+    x = torch.from_numpy(b['x']).to(dev); m = torch.from_numpy(b['mask']).to(dev)
+    y = torch.from_numpy(b['y']).to(dev)
+    vals = [v.astype(np.float64) for v in net.get_all_param_values()]
+    mo = [np.zeros_like(v) for v in vals]; vo = [np.zeros_like(v) for v in vals]
+    t = 0
+    for _ in range(3):
+        net.loss(x, m, y, m); net.backward()
+        g = [v.astype(np.float64) for v in net.get_all_grad_values()]
+        gn = net.adam_update(1e-3).item()
+        t = O.adam_step(vals, g, mo, vo, t)
+        np.testing.assert_allclose(gn, np.sqrt(sum((gi ** 2).sum() for gi in g)), rtol=1e-5)
+    for a, o in zip(net.get_all_param_values(), vals):
+        assert relerr(a, o) < 1e-5
