@@ -62,6 +62,12 @@ _SIGS = {
     'asr_lstm_scan_fwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),
     'asr_lstm_scan_bwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),
     'asr_scan_status': (i32, [fp, i32]),
+    'asr_perm4': (i32, [fp, fp, i32, i32, i32, fp]),
+    'asr_hyper_pack_floats': (sz, [i32, i32, i32]),
+    'asr_hyper_pack_w': (i32, [fp, fp, fp, fp, i32, i32, i32, fp, fp]),
+    'asr_hyper_scan_ws_bytes': (sz, [i32, i32, i32, i32, i32, i32]),
+    'asr_hyper_scan_fwd': (i32, [C.POINTER(HyperScanDesc), fp, sz, fp]),
+    'asr_hyper_scan_bwd': (i32, [C.POINTER(HyperScanDesc), fp, sz, fp]),
 }
 
 _lib = None

@@ -283,3 +283,26 @@ extern "C" int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, cons
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
+
+// ------------------------------------------------------------------ gate-major <-> gate-interleaved
+// dir 0: dst[r][u*4+g] = src[r][g*N+u]   (reference stacking -> engine layout);  dir 1: inverse
+__global__ void perm4_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int N,
+                             int dir) {
+    const size_t tot = rows * 4 * (size_t)N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (4 * (size_t)N);
+        const int c = (int)(i % (4 * (size_t)N));
+        if (dir == 0) { const int u = c >> 2, g = c & 3; dst[i] = src[r * 4 * N + (size_t)g * N + u]; }
+        else          { const int g = c / N, u = c % N;  dst[i] = src[r * 4 * N + (size_t)u * 4 + g]; }
+    }
+}
+extern "C" int asr_perm4(const float* src, float* dst, int rows, int N, int dir, hipStream_t stream) {
+    if (rows < 0 || N <= 0 || !src || !dst) return ASR_ERR_ARG;
+    size_t tot = (size_t)rows * 4 * N;
+    if (!tot) return ASR_OK;
+    int grid = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+    hipLaunchKernelGGL(perm4_kernel, dim3(grid), dim3(256), 0, stream, src, dst, (size_t)rows, N, dir);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

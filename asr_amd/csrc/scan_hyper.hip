@@ -1,0 +1,661 @@
+// K2 (HyperLSTM): persistent recurrent scan, forward and BPTT, for
+//   libs/lasagne_libs/hyper_lhuc_layers.py:216-237 (eq.10 hyper cell), :363-412 (step),
+//   :414-425 (step_masked), :493-500 (theano.scan over [orig_input, input, mask]).
+//
+// Host-side preparation (asr_amd/engine_hyper.py):
+//   * xproj  = x.W_x (T,B,4N)                                   (:469)
+//   * xhproj = x.W_xhat[N:] + bhat (T,B,4H): the x_t half of eq.10's [h_{t-1}, x_t].W_xhat hoisted
+//     out of the loop ([h,x].W = h.W[:N] + x.W[N:], exact algebra)
+//   * eq.11 and eq.12 folded: d = (hhat.W_hhat + b).W_z = hhat.(W_hhat.W_z) + b.W_z, so the step
+//     goes hhat_t -> d_h, d_x, bias in ONE product with M (H x 12N) (+ constant row), removing the
+//     z exchange; the factors' gradients are recovered from dM after the scan.
+// Group = G = N/4 workgroups; workgroup j owns main units 4j..4j+3 and hyper units j*UH..j*UH+UH-1.
+// Per step two exchanges: hhat_t (after the hyper cell) and h_t (after the main cell).
+#include "scan_common.h"
+
+struct HyperDir {
+    int reverse;
+    const float* xproj;      // (T,B,4N)
+    const float* xhproj;     // (T,B,4H)
+    const float* wpack;      // asr_hyper_pack_w (mode 0 fwd / 1 bwd)
+    const float* cvec;       // (12N) = row H of the folded matrix: [c_h | c_x | c_b], interleaved
+    float* r_out; int ld_r;  // (T,B,ld_r) h_t
+    float* hh_out;           // (T,B,H)  hhat_t
+    float* gates;            // (T,B,4N) post-activation
+    float* cst;              // (T,B,N)
+    float* hgates;           // (T,B,4H)
+    float* hcst;             // (T,B,H)
+    float* aD;               // (T,B,3,4N): a = h_{t-1}.W_h, d_h, d_x
+    const float* dr_ext; int ld_dr;
+    float* dXp;              // (T,B,4N) dgates * d_x           -> dW_x, dx
+    float* dXh;              // (T,B,4H) clipped hyper gate grads -> dW_xhat, dbhat, dW_hhat, dx
+    float* dA;               // (T,B,4N) dgates * d_h           -> dW_h
+    float* dD;               // (T,B,3,4N) [dgates*a, dgates*xproj, dgates] -> dM, dcvec
+};
+
+struct HyperArgs {
+    int T, B, N, H, G, UH, KS, KSP, KT, HS, HSP, HT;
+    int ndir, chunk0;
+    float clip;
+    const float* mask; int msb, mst;
+    HyperDir d[2];
+    unsigned* sync;
+    float* rex;      // [ng][2][KS][64]
+    float* hex;      // [ng][2][G][64]
+    float* dex;      // [ng][2][KS dst][G src][64]
+    float* dhx;      // [ng][2][G dst][G src][UH*16]
+    float* dgx;      // [ng][2][H][16][4]
+};
+
+static inline void hyper_dims(int N, int H, HyperArgs* A) {
+    A->N = N; A->H = H;
+    A->G = N / 4;
+    A->KS = N / 4; A->KSP = ((A->KS + 15) / 16) * 16; A->KT = (N + 15) / 16;
+    A->HS = H / 4; A->HSP = ((A->HS + 15) / 16) * 16; A->HT = (H + 15) / 16;
+    int uh = 1;
+    while (uh * A->G < H) uh *= 2;
+    A->UH = uh;
+}
+static inline size_t hyper_pack_floats_wg(const HyperArgs& A, int mode) {
+    const int CR = 4 * A.UH;
+    const int S4P = ((A.H + 15) / 16) * 16;
+    if (mode == 0) return (size_t)A.KSP * 64 + (size_t)(A.KSP + A.HSP) * 4 * CR + (size_t)3 * A.HSP * 64;
+    return (size_t)A.KT * 256 + (size_t)A.HT * 3 * 256 + (size_t)S4P * 4 * (4 + A.UH);
+}
+
+// ------------------------------------------------------------------------------------------------
+// packing: one thread block per workgroup slice
+__global__ void hyper_pack_kernel(const float* __restrict__ Wh, const float* __restrict__ Whx,
+                                  const float* __restrict__ Whh, const float* __restrict__ M, HyperArgs A,
+                                  int mode, size_t per_wg, float* __restrict__ out) {
+    const int j = blockIdx.x;
+    const int N = A.N, H = A.H, UH = A.UH, CR = 4 * UH;
+    float* o = out + (size_t)j * per_wg;
+    if (mode == 0) {
+        const size_t n1 = (size_t)A.KSP * 64;
+        for (size_t i = threadIdx.x; i < n1; i += blockDim.x) {
+            const int e = i & 3, l = (i >> 2) & 63, s4 = (int)(i >> 8);
+            const int row = 4 * (4 * s4 + e) + (l >> 4), col = j * 16 + (l & 15);
+            o[i] = row < N ? Wh[(size_t)row * 4 * N + col] : 0.f;
+        }
+        float* og = o + n1;
+        const size_t n2 = (size_t)(A.KSP + A.HSP) * 4 * CR;
+        for (size_t i = threadIdx.x; i < n2; i += blockDim.x) {
+            const int e = i & 3;
+            const int ic = (int)((i >> 2) % CR);
+            const int qq = (int)((i >> 2) / CR) & 3;
+            const int s4g = (int)((i >> 2) / CR) >> 2;           // over KSP/4 + HSP/4 groups
+            const int hu = j * UH + ic / 4;
+            const int col = hu * 4 + (ic & 3);
+            float v = 0.f;
+            if (hu < H) {
+                if (s4g < A.KSP / 4) {
+                    const int row = 4 * (4 * s4g + e) + qq;
+                    if (row < N) v = Whx[(size_t)row * 4 * H + col];
+                } else {
+                    const int row = 4 * (4 * (s4g - A.KSP / 4) + e) + qq;
+                    if (row < H) v = Whh[(size_t)row * 4 * H + col];
+                }
+            }
+            og[i] = v;
+        }
+        float* od = og + n2;
+        const size_t n3 = (size_t)3 * A.HSP * 64;
+        for (size_t i = threadIdx.x; i < n3; i += blockDim.x) {
+            const int e = i & 3, l = (i >> 2) & 63;
+            const int s4 = (int)((i >> 8) % (A.HSP / 4)), tau = (int)((i >> 8) / (A.HSP / 4));
+            const int row = 4 * (4 * s4 + e) + (l >> 4);
+            od[i] = row < H ? M[(size_t)row * 12 * N + (size_t)tau * 4 * N + j * 16 + (l & 15)] : 0.f;
+        }
+    } else {
+        const size_t n1 = (size_t)A.KT * 256;
+        for (size_t i = threadIdx.x; i < n1; i += blockDim.x) {
+            const int e = i & 3, l = (i >> 2) & 63, kt = (int)(i >> 8);
+            const int row = kt * 16 + (l & 15), col = j * 16 + 4 * e + (l >> 4);
+            o[i] = row < N ? Wh[(size_t)row * 4 * N + col] : 0.f;
+        }
+        float* om = o + n1;
+        const size_t n2 = (size_t)A.HT * 3 * 256;
+        for (size_t i = threadIdx.x; i < n2; i += blockDim.x) {
+            const int e = i & 3, l = (i >> 2) & 63;
+            const int tau = (int)((i >> 8) % 3), ht = (int)((i >> 8) / 3);
+            const int hu = ht * 16 + (l & 15);
+            om[i] = hu < H ? M[(size_t)hu * 12 * N + (size_t)tau * 4 * N + j * 16 + 4 * e + (l >> 4)] : 0.f;
+        }
+        float* orw = om + n2;
+        const int S4P = ((H + 15) / 16) * 16;
+        const int RR = 4 + UH;
+        const size_t n3 = (size_t)S4P * 4 * RR;
+        for (size_t i = threadIdx.x; i < n3; i += blockDim.x) {
+            const int e = i & 3, ir = (int)((i >> 2) % RR), qq = (int)(((i >> 2) / RR) & 3);
+            const int s4 = (int)(((i >> 2) / RR) >> 2);
+            const int col = 4 * (4 * s4 + e) + qq;              // column of the 4H-wide hyper gate vector
+            float v = 0.f;
+            if (col < 4 * H) {
+                if (ir < 4) v = Whx[(size_t)(j * 4 + ir) * 4 * H + col];
+                else if (ir - 4 < UH && j * UH + ir - 4 < H) v = Whh[(size_t)(j * UH + ir - 4) * 4 * H + col];
+            }
+            orw[i] = v;
+        }
+    }
+}
+
+extern "C" size_t asr_hyper_pack_floats(int N, int H, int mode) {
+    HyperArgs A;
+    hyper_dims(N, H, &A);
+    return hyper_pack_floats_wg(A, mode) * A.G;
+}
+
+// Wh (N,4N), Whx (N,4H) = rows [0,N) of W_xhat, Whh (H,4H), M (H,12N): all gate-interleaved.
+extern "C" int asr_hyper_pack_w(const float* Wh, const float* Whx, const float* Whh, const float* M, int N,
+                                int H, int mode, float* out, hipStream_t stream) {
+    if (!Wh || !Whx || !Whh || !M || !out || N <= 0 || H <= 0 || (N & 3) || (H & 3) || H > N) return ASR_ERR_ARG;
+    HyperArgs A;
+    hyper_dims(N, H, &A);
+    if (A.UH > 4) return ASR_ERR_ARG;
+    hipLaunchKernelGGL(hyper_pack_kernel, dim3(A.G), dim3(256), 0, stream, Wh, Whx, Whh, M, A, mode,
+                       hyper_pack_floats_wg(A, mode), out);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = A.N, H = A.H, UH = A.UH, CR = 4 * UH, KS = A.KS, KSP = A.KSP, HS = A.HS, HSP = A.HSP;
+    const int T = A.T, B = A.B, G = A.G;
+    float* Wm = smem;                                           // [KSP/4][64][4]
+    float* Wg = Wm + (size_t)KSP * 64;                          // [(KSP+HSP)/4][4][CR][4]
+    float* Wd = Wg + (size_t)(KSP + HSP) * 4 * CR;              // [3][HSP/4][64][4]
+    float* red = Wd + (size_t)3 * HSP * 64;                     // [3 tiles][4 waves][64][4]
+    int* flag = (int*)(red + 3 * 4 * 256);
+
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
+    const int grp = chunk * A.ndir + dir;
+    const HyperDir& D = A.d[dir];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, bl = lane & 15;
+    const int b = chunk * 16 + bl;
+    const bool bvalid = b < B;
+
+    GroupSync gs;
+    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
+    gs.G = G; gs.epoch = 0;
+    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
+    gs.lds_flag = flag;
+    {
+        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * per_wg);
+        f32x4* dst = (f32x4*)smem;
+        for (size_t i = tid; i < per_wg / 4; i += 256) dst[i] = src[i];
+    }
+    float* rex = A.rex + (size_t)grp * 2 * KS * 64;
+    float* hex = A.hex + (size_t)grp * 2 * G * 64;
+
+    const int unit = j * 4 + q;                  // wave 0: main unit of this lane
+    const int col4 = unit * 4;
+    const int hu = j * UH + q;                   // wave 1: hyper unit of this lane (valid if q < UH)
+    const bool hvalid = (q < UH) && (hu < H);
+    float c = 0.f, r = 0.f, hc = 0.f, hh = 0.f;
+    f32x4 cv_h = {0, 0, 0, 0}, cv_x = {0, 0, 0, 0}, cv_b = {0, 0, 0, 0};
+    if (wave == 0) {
+        cv_h = *(const f32x4*)(D.cvec + col4);
+        cv_x = *(const f32x4*)(D.cvec + 4 * N + col4);
+        cv_b = *(const f32x4*)(D.cvec + 8 * N + col4);
+        st_sc1(rex + (size_t)j * 64 + lane, 0.f);
+    }
+    if (wave == 1) st_sc1(hex + (size_t)j * 64 + lane, 0.f);
+    group_publish(gs);
+
+    const int ks4 = KSP / 16, hs4 = HSP / 16;    // b128 groups per wave
+    for (int step = 0; step < T; ++step) {
+        const int t = D.reverse ? T - 1 - step : step;
+        const int par = step & 1;
+        const size_t row = (size_t)t * B + b;
+        f32x4 x4 = {0, 0, 0, 0}, xh4 = {0, 0, 0, 0};
+        float m = 0.f;
+        if (bvalid && wave < 2) m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
+        if (wave == 0 && bvalid) x4 = *(const f32x4*)(D.xproj + row * 4 * N + col4);
+        if (wave == 1 && bvalid && hvalid) xh4 = *(const f32x4*)(D.xhproj + row * 4 * H + hu * 4);
+        if (!group_wait(gs)) break;
+
+        // ---- phase 1: a = h.W_h (main tile) and hyper gate pre-activations, K split over waves
+        const float* rp = rex + (size_t)par * KS * 64;
+        const float* hp = hex + (size_t)par * G * 64;
+        f32x4 am0 = {0, 0, 0, 0}, am1 = {0, 0, 0, 0}, ag0 = {0, 0, 0, 0}, ag1 = {0, 0, 0, 0};
+        const int ic = (bl < CR ? bl : CR - 1);
+        for (int g4 = 0; g4 < ks4; ++g4) {
+            const int s4 = wave * ks4 + g4;
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int s = s4 * 4 + e;
+                bv[e] = s < KS ? ld_sc1(rp + (size_t)s * 64 + lane) : 0.f;
+            }
+            const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
+            const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
+            am0 = mfma4(av[0], bv[0], am0); ag0 = mfma4(gv[0], bv[0], ag0);
+            am1 = mfma4(av[1], bv[1], am1); ag1 = mfma4(gv[1], bv[1], ag1);
+            am0 = mfma4(av[2], bv[2], am0); ag0 = mfma4(gv[2], bv[2], ag0);
+            am1 = mfma4(av[3], bv[3], am1); ag1 = mfma4(gv[3], bv[3], ag1);
+        }
+        for (int g4 = 0; g4 < hs4; ++g4) {
+            const int s4 = wave * hs4 + g4;
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hq = (s4 * 4 + e) * 4 + q;             // hyper unit feeding this k index
+                bv[e] = hq < H ? ld_sc1(hp + (size_t)(hq / UH) * 64 + (hq % UH) * 16 + bl) : 0.f;
+            }
+            const f32x4 gv = *(const f32x4*)(Wg + (((size_t)(KSP / 4 + s4) * 4 + q) * CR + ic) * 4);
+            ag0 = mfma4(gv[0], bv[0], ag0); ag1 = mfma4(gv[1], bv[1], ag1);
+            ag0 = mfma4(gv[2], bv[2], ag0); ag1 = mfma4(gv[3], bv[3], ag1);
+        }
+        *(f32x4*)(red + ((size_t)(0 * 4 + wave) * 64 + lane) * 4) = am0 + am1;
+        *(f32x4*)(red + ((size_t)(1 * 4 + wave) * 64 + lane) * 4) = ag0 + ag1;
+        __syncthreads();
+        f32x4 a4 = {0, 0, 0, 0};
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(0 * 4 + w) * 64 + lane) * 4);
+        }
+        if (wave == 1) {          // hyper cell, eq.10 (:226-235)
+            f32x4 hg = xh4;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) hg += *(const f32x4*)(red + ((size_t)(1 * 4 + w) * 64 + lane) * 4);
+            const float hi = sigmoidf_(hg[0]), hf = sigmoidf_(hg[1]), hgc = tanhf_(hg[2]), ho = sigmoidf_(hg[3]);
+            const float hc_new = hf * hc + hi * hgc;
+            const float hh_new = ho * tanhf_(hc_new);
+            if (m != 0.f && hvalid) { hc = hc_new; hh = hh_new; }
+            st_sc1(hex + ((size_t)(par ^ 1) * G + j) * 64 + lane, hvalid ? hh : 0.f);
+            if (bvalid && hvalid) {
+                D.hh_out[row * H + hu] = hh;
+                if (D.hgates) {
+                    *(f32x4*)(D.hgates + row * 4 * H + hu * 4) = f32x4{hi, hf, hgc, ho};
+                    D.hcst[row * H + hu] = hc;
+                }
+            }
+        }
+        group_publish(gs);
+        if (!group_wait(gs)) break;
+
+        // ---- phase 2: d_h, d_x, bias = hhat_t . M  (3 tiles), then the main cell
+        const float* hn = hex + (size_t)(par ^ 1) * G * 64;
+        f32x4 ad[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int g4 = 0; g4 < hs4; ++g4) {
+            const int s4 = wave * hs4 + g4;
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hq = (s4 * 4 + e) * 4 + q;
+                bv[e] = hq < H ? ld_sc1(hn + (size_t)(hq / UH) * 64 + (hq % UH) * 16 + bl) : 0.f;
+            }
+#pragma unroll
+            for (int tau = 0; tau < 3; ++tau) {
+                const f32x4 dv = *(const f32x4*)(Wd + (((size_t)tau * (HSP / 4) + s4) * 64 + lane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ad[tau] = mfma4(dv[e], bv[e], ad[tau]);
+            }
+        }
+#pragma unroll
+        for (int tau = 0; tau < 3; ++tau) *(f32x4*)(red + ((size_t)(tau * 4 + wave) * 64 + lane) * 4) = ad[tau];
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 dh4 = cv_h, dx4 = cv_x, bb4 = cv_b;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                dh4 += *(const f32x4*)(red + ((size_t)(0 * 4 + w) * 64 + lane) * 4);
+                dx4 += *(const f32x4*)(red + ((size_t)(1 * 4 + w) * 64 + lane) * 4);
+                bb4 += *(const f32x4*)(red + ((size_t)(2 * 4 + w) * 64 + lane) * 4);
+            }
+            const f32x4 pre = a4 * dh4 + (x4 * dx4 + bb4);       // :393-395
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            const float c_new = fg * c + ig * gg;
+            const float r_new = og * tanhf_(c_new);
+            if (m != 0.f) { c = c_new; r = r_new; }
+            st_sc1(rex + ((size_t)(par ^ 1) * KS + j) * 64 + lane, r);
+            if (bvalid) {
+                D.r_out[row * D.ld_r + unit] = r;
+                if (D.gates) {
+                    D.cst[row * N + unit] = c;
+                    *(f32x4*)(D.gates + row * 4 * N + col4) = f32x4{ig, fg, gg, og};
+                    float* ad_ = D.aD + row * 12 * N;
+                    *(f32x4*)(ad_ + col4) = a4;
+                    *(f32x4*)(ad_ + 4 * N + col4) = dh4;
+                    *(f32x4*)(ad_ + 8 * N + col4) = dx4;
+                }
+            }
+        }
+        group_publish(gs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = A.N, H = A.H, UH = A.UH, KS = A.KS, KT = A.KT, HT = A.HT;
+    const int T = A.T, B = A.B, G = A.G;
+    const int S4P = ((H + 15) / 16) * 16;
+    const int UHB = UH * 16;
+    float* Wb = smem;                                   // [KT][64][4]
+    float* Mb = Wb + (size_t)KT * 256;                  // [HT][3][64][4]
+    float* Rw = Mb + (size_t)HT * 3 * 256;              // [S4P/4][4][4+UH][4]
+    float* dal = Rw + (size_t)S4P * 4 * (4 + UH);                 // [16 cols][16 b]            da
+    float* dDl = dal + 256;                             // [3][16 cols][16 b]         dD
+    float* rsum = dDl + 768;                            // [16 sg][16][4]             dex gather
+    float* hsum = rsum + 1024;                          // [256]                      dhx gather partials
+    float* red = hsum + 256;                            // [4 waves][64][4]           Rw product
+    int* flag = (int*)(red + 1024);
+
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
+    const int grp = chunk * A.ndir + dir;
+    const HyperDir& D = A.d[dir];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, bl = lane & 15;
+    const int b = chunk * 16 + bl;
+    const bool bvalid = b < B;
+
+    GroupSync gs;
+    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
+    gs.G = G; gs.epoch = 0;
+    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
+    gs.lds_flag = flag;
+    {
+        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * per_wg);
+        f32x4* dst = (f32x4*)smem;
+        for (size_t i = tid; i < per_wg / 4; i += 256) dst[i] = src[i];
+    }
+    float* dex = A.dex + (size_t)grp * 2 * KS * G * 64;
+    float* dhx = A.dhx + (size_t)grp * 2 * G * G * UHB;
+    float* dgx = A.dgx + (size_t)grp * 2 * H * 64;
+    const __amdgpu_buffer_rsrc_t dex_rs = make_rsrc_(dex, (unsigned)((size_t)2 * KS * G * 64 * 4));
+
+    const int unit = j * 4 + q, col4 = unit * 4;
+    const int hu = j * UH + q;
+    const bool hvalid = (q < UH) && (hu < H);
+    float dc = 0.f, dh_pass = 0.f, dh_hyp = 0.f;        // wave 0 lanes
+    float dhc = 0.f, dhh_pass = 0.f, dhh_rec = 0.f;     // wave 1 lanes
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int st = T - 1 - step;
+        const int t = D.reverse ? T - 1 - st : st;
+        const int tprev = D.reverse ? t + 1 : t - 1;
+        const int par = step & 1;
+        const size_t row = (size_t)t * B + b, rowp = (size_t)tprev * B + b;
+        float m = 0.f;
+        if (bvalid && wave < 2) m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
+        const bool on = (m != 0.f);
+
+        // ---- S1: main cell backward (wave 0)
+        if (wave == 0) {
+            f32x4 g4 = {0, 0, 0, 0}, a4 = {0, 0, 0, 0}, dh4 = {0, 0, 0, 0}, dx4 = {0, 0, 0, 0}, x4 = {0, 0, 0, 0};
+            float c_new = 0.f, c_prev = 0.f, dre = 0.f;
+            if (bvalid) {
+                g4 = *(const f32x4*)(D.gates + row * 4 * N + col4);
+                const float* ad_ = D.aD + row * 12 * N;
+                a4 = *(const f32x4*)(ad_ + col4);
+                dh4 = *(const f32x4*)(ad_ + 4 * N + col4);
+                dx4 = *(const f32x4*)(ad_ + 8 * N + col4);
+                x4 = *(const f32x4*)(D.xproj + row * 4 * N + col4);
+                c_new = D.cst[row * N + unit];
+                c_prev = st > 0 ? D.cst[rowp * N + unit] : 0.f;
+                dre = D.dr_ext[row * D.ld_dr + unit];
+            }
+            // dh_sum: contributions published at the end of the previous backward step
+            float dh_sum = 0.f;
+            if (step > 0) {
+#pragma unroll
+                for (int sgi = 0; sgi < 16; ++sgi) dh_sum += rsum[((size_t)sgi * 16 + bl) * 4 + q];
+            }
+            const float dh_t = dre + dh_pass + dh_sum + dh_hyp;
+            f32x4 dg4 = {0, 0, 0, 0};
+            if (on) {
+                const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
+                const float tc = tanhf_(c_new);
+                const float do_ = dh_t * tc;
+                const float dct = dc + dh_t * og * (1.f - tc * tc);
+                dg4[0] = clipf_(dct * gg * ig * (1.f - ig), A.clip);
+                dg4[1] = clipf_(dct * c_prev * fg * (1.f - fg), A.clip);
+                dg4[2] = clipf_(dct * ig * (1.f - gg * gg), A.clip);
+                dg4[3] = clipf_(do_ * og * (1.f - og), A.clip);
+                dc = dct * fg;
+                dh_pass = 0.f;
+            } else {
+                dh_pass = dh_t;
+            }
+            const f32x4 da4 = dg4 * dh4;
+            const f32x4 dd_h = dg4 * a4, dd_x = dg4 * x4;
+            if (bvalid) {
+                *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
+                *(f32x4*)(D.dXp + row * 4 * N + col4) = dg4 * dx4;
+                float* dd_ = D.dD + row * 12 * N;
+                *(f32x4*)(dd_ + col4) = dd_h;
+                *(f32x4*)(dd_ + 4 * N + col4) = dd_x;
+                *(f32x4*)(dd_ + 8 * N + col4) = dg4;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dal[(q * 4 + k) * 16 + bl] = da4[k];
+                dDl[0 * 256 + (q * 4 + k) * 16 + bl] = dd_h[k];
+                dDl[1 * 256 + (q * 4 + k) * 16 + bl] = dd_x[k];
+                dDl[2 * 256 + (q * 4 + k) * 16 + bl] = dg4[k];
+            }
+        }
+        __syncthreads();
+        // ---- S2: partial dh_{prev} (-> dex) and partial dhhat_t (-> dhx)
+        if (step + 1 < T) {
+            for (int kt = wave; kt < KT; kt += 4) {
+                f32x4 acc = {0, 0, 0, 0};
+                const f32x4 av = *(const f32x4*)(Wb + ((size_t)kt * 64 + lane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma4(av[e], dal[(4 * e + q) * 16 + bl], acc);
+                const int dst = kt * 4 + q;
+                if (dst < KS)
+                    st_sc1_f4(dex_rs, (unsigned)(((((size_t)par * KS + dst) * G + j) * 64 + bl * 4) * 4), acc);
+            }
+        }
+        for (int ht = wave; ht < HT; ht += 4) {
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int tau = 0; tau < 3; ++tau) {
+                const f32x4 mv = *(const f32x4*)(Mb + (((size_t)ht * 3 + tau) * 64 + lane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma4(mv[e], dDl[tau * 256 + (4 * e + q) * 16 + bl], acc);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int hq = ht * 16 + q * 4 + rg;              // hyper unit of this accumulator reg
+                if (hq < H)
+                    st_sc1(dhx + (((size_t)par * G + hq / UH) * G + j) * UHB + (hq % UH) * 16 + bl, acc[rg]);
+            }
+        }
+        group_publish(gs);
+        if (!group_wait(gs)) break;
+        // ---- S3: gather dhx for own hyper units; gather dex for own main units (used next step)
+        {
+            const int e = tid % UHB, s0 = tid / UHB, sstep = 256 / UHB;
+            float acc = 0.f;
+            const float* base = dhx + ((size_t)par * G + j) * G * UHB;
+            for (int src = s0; src < G; src += sstep) acc += ld_sc1(base + (size_t)src * UHB + e);
+            hsum[tid] = acc;
+        }
+        if (step + 1 < T) {
+            const int sg = tid >> 4, f4 = tid & 15;
+            f32x4 acc = {0, 0, 0, 0};
+            const size_t base = (((size_t)par * KS + j) * G) * 64;
+            for (int src = sg; src < G; src += 16)
+                acc += ld_sc1_f4(dex_rs, (unsigned)((base + (size_t)src * 64 + f4 * 4) * 4));
+            *(f32x4*)(rsum + ((size_t)sg * 16 + f4) * 4) = acc;
+        }
+        __syncthreads();
+        // ---- S4: hyper cell backward (wave 1)
+        if (wave == 1) {
+            f32x4 dhg = {0, 0, 0, 0};
+            if (hvalid) {
+                float dsum = 0.f;
+                const int sstep = 256 / UHB;
+                for (int k = 0; k < sstep; ++k) dsum += hsum[k * UHB + q * 16 + bl];
+                f32x4 hg4 = {0, 0, 0, 0};
+                float hc_new = 0.f, hc_prev = 0.f;
+                if (bvalid) {
+                    hg4 = *(const f32x4*)(D.hgates + row * 4 * H + hu * 4);
+                    hc_new = D.hcst[row * H + hu];
+                    hc_prev = st > 0 ? D.hcst[rowp * H + hu] : 0.f;
+                }
+                const float dhh_t = dhh_pass + dhh_rec;          // gradient wrt the state hhat_t
+                if (on) {
+                    const float dhh_new = dhh_t + dsum;          // + via d = hhat_new.M of this step
+                    const float hi = hg4[0], hf = hg4[1], hgc = hg4[2], ho = hg4[3];
+                    const float thc = tanhf_(hc_new);
+                    const float dho = dhh_new * thc;
+                    const float dhct = dhc + dhh_new * ho * (1.f - thc * thc);
+                    dhg[0] = clipf_(dhct * hgc * hi * (1.f - hi), A.clip);
+                    dhg[1] = clipf_(dhct * hc_prev * hf * (1.f - hf), A.clip);
+                    dhg[2] = clipf_(dhct * hi * (1.f - hgc * hgc), A.clip);
+                    dhg[3] = clipf_(dho * ho * (1.f - ho), A.clip);
+                    dhc = dhct * hf;
+                    dhh_pass = 0.f;
+                } else {
+                    dhh_pass = dhh_t;
+                }
+                if (bvalid) *(f32x4*)(D.dXh + row * 4 * H + hu * 4) = dhg;
+                // all-gather payload: dgx[par][hu][b][gate]
+                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 0, dhg[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 1, dhg[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 2, dhg[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 3, dhg[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (step + 1 == T) break;                       // nothing consumes the last step's feedback
+        group_publish(gs);
+        if (!group_wait(gs)) break;
+        // ---- S5: own rows of [W_xhat[:N] ; W_hhat] times the gathered hyper gate grads
+        {
+            f32x4 acc = {0, 0, 0, 0};
+            const float* gp = dgx + (size_t)par * H * 64;
+            const int RR = 4 + UH;
+            const int ir = (bl < RR ? bl : RR - 1);
+            const int n4 = S4P / 16;
+            for (int g4 = 0; g4 < n4; ++g4) {
+                const int s4 = wave * n4 + g4;
+                const f32x4 rv = *(const f32x4*)(Rw + (((size_t)s4 * 4 + q) * RR + ir) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int s = s4 * 4 + e;                    // hyper unit index; k = gate q
+                    const float bv = s < H ? ld_sc1(gp + ((size_t)s * 16 + bl) * 4 + q) : 0.f;
+                    acc = mfma4(rv[e], bv, acc);
+                }
+            }
+            *(f32x4*)(red + ((size_t)wave * 64 + lane) * 4) = acc;
+        }
+        __syncthreads();
+        // output rows i = q*4+reg: i<4 -> main unit i (lanes q==0, reg=i); i=4+uh -> hyper (q==1, reg=uh)
+        if (wave == 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[((size_t)w * 64 + (0 * 16 + bl)) * 4 + q];
+            dh_hyp = v;
+        }
+        if (wave == 1) {
+            float v = 0.f;
+            if (q < UH) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += red[((size_t)w * 64 + (1 * 16 + bl)) * 4 + q];
+            }
+            dhh_rec = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct asr_hyper_scan_desc {
+    int T, B, N, H, ndir;
+    float grad_clip;
+    const float* mask; int mask_stride_b, mask_stride_t;
+    HyperDir dir[2];
+};
+
+extern "C" size_t asr_hyper_scan_ws_bytes(int T, int B, int N, int H, int ndir, int backward) {
+    (void)T;
+    HyperArgs A;
+    hyper_dims(N, H, &A);
+    const size_t ng = (size_t)ndir * ((B + 15) / 16);
+    size_t bytes = ng * SYNC_STRIDE * 4;
+    bytes += ng * 2 * A.KS * 64 * 4 + ng * 2 * A.G * 64 * 4;
+    if (backward) {
+        bytes += ng * 2 * (size_t)A.KS * A.G * 64 * 4;
+        bytes += ng * 2 * (size_t)A.G * A.G * A.UH * 16 * 4;
+        bytes += ng * 2 * (size_t)H * 64 * 4;
+    }
+    return bytes + 1024;
+}
+
+static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, int backward,
+                        hipStream_t stream) {
+    if (!d || !ws || d->T < 0 || d->B <= 0 || d->N <= 0 || d->H <= 0 || (d->N & 3) || (d->H & 3) ||
+        d->H > d->N || d->ndir < 1 || d->ndir > 2 || !d->mask)
+        return ASR_ERR_ARG;
+    HyperArgs A;
+    hyper_dims(d->N, d->H, &A);
+    if (A.UH > 4) return ASR_ERR_ARG;
+    for (int k = 0; k < d->ndir; ++k) {
+        const HyperDir& D = d->dir[k];
+        if (!D.wpack || !D.xproj) return ASR_ERR_ARG;
+        if (!backward && (!D.xhproj || !D.cvec || !D.r_out || !D.hh_out)) return ASR_ERR_ARG;
+        if (backward && (!D.gates || !D.cst || !D.hgates || !D.hcst || !D.aD || !D.dr_ext || !D.dXp ||
+                         !D.dXh || !D.dA || !D.dD))
+            return ASR_ERR_ARG;
+    }
+    if (ws_bytes < asr_hyper_scan_ws_bytes(d->T, d->B, d->N, d->H, d->ndir, backward)) return ASR_ERR_WS;
+    if (d->T == 0) return ASR_OK;
+    if (A.G * d->ndir > 256) return ASR_ERR_ARG;         // co-residency bound of the persistent grid
+    A.T = d->T; A.B = d->B; A.ndir = d->ndir; A.clip = d->grad_clip;
+    A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
+    A.d[0] = d->dir[0]; A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
+    const int nchunk = (d->B + 15) / 16;
+    const size_t ng = (size_t)d->ndir * nchunk;
+    char* p = (char*)ws;
+    A.sync = (unsigned*)p;  p += ng * SYNC_STRIDE * 4;
+    A.rex = (float*)p;      p += ng * 2 * A.KS * 64 * 4;
+    A.hex = (float*)p;      p += ng * 2 * A.G * 64 * 4;
+    A.dex = A.dhx = A.dgx = nullptr;
+    if (backward) {
+        A.dex = (float*)p;  p += ng * 2 * (size_t)A.KS * A.G * 64 * 4;
+        A.dhx = (float*)p;  p += ng * 2 * (size_t)A.G * A.G * A.UH * 16 * 4;
+        A.dgx = (float*)p;
+    }
+    if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
+    const size_t per_wg = hyper_pack_floats_wg(A, backward);
+    size_t lds;
+    if (!backward) lds = (per_wg + 3 * 4 * 256) * 4 + 64;
+    else lds = (per_wg + 256 + 768 + 1024 + 256 + 1024) * 4 + 64;
+    if (lds > 160 * 1024) return ASR_ERR_ARG;
+    int cpl = 256 / (A.G * d->ndir);
+    if (cpl > nchunk) cpl = nchunk;
+    for (int c0 = 0; c0 < nchunk; c0 += cpl) {
+        const int nc = nchunk - c0 < cpl ? nchunk - c0 : cpl;
+        A.chunk0 = c0;
+        dim3 grid(A.G, d->ndir, nc), block(256);
+        if (!backward) {
+            hipFuncSetAttribute((const void*)hyper_scan_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(hyper_scan_fwd_kernel, grid, block, lds, stream, A, per_wg);
+        } else {
+            hipFuncSetAttribute((const void*)hyper_scan_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(hyper_scan_bwd_kernel, grid, block, lds, stream, A, per_wg);
+        }
+        ASR_CHECK_LAUNCH();
+    }
+    return ASR_OK;
+}
+
+extern "C" int asr_hyper_scan_fwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return hyper_launch(d, ws, ws_bytes, 0, stream);
+}
+extern "C" int asr_hyper_scan_bwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return hyper_launch(d, ws, ws_bytes, 1, stream);
+}

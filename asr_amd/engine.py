@@ -595,6 +595,16 @@ class Network(object):
         self._last_groups = getattr(self, '_last_groups', {})
         self._last_groups[('lstm', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
 
+    def scan_hyper(self, pair, desc, backward):
+        L = _lib.lib()
+        need = L.asr_hyper_scan_ws_bytes(desc.T, desc.B, desc.N, desc.H, desc.ndir, int(backward))
+        ws = self._workspace(('hyper', pair.idx, backward), need)
+        fn = L.asr_hyper_scan_bwd if backward else L.asr_hyper_scan_fwd
+        check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+              'asr_hyper_scan_%s' % ('bwd' if backward else 'fwd'))
+        self._last_groups = getattr(self, '_last_groups', {})
+        self._last_groups[('hyper', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
+
     def check_status(self):
         """Call after a host sync: raises if any persistent scan gave up on a bounded wait."""
         torch.cuda.synchronize(self.device)

@@ -1,0 +1,181 @@
+"""HyperLSTM layer pair (libs/lasagne_libs/hyper_lhuc_layers.py:168-507) on the persistent
+HyperLSTM scan kernel.  See asr_amd/csrc/scan_hyper.hip for what is hoisted / folded."""
+import ctypes as C
+import torch
+
+from . import _lib, ops, specs
+from ._lib import check
+from .engine import DirParams
+
+G4 = specs.GATES_LHUC
+
+
+def _mk_hyper(store, prefix, D, N, H, Z):
+    dp = DirParams(store, prefix)
+    dp.add('Whh', (H, 4 * H)); dp.add('Wxh', (N + D, 4 * H)); dp.add('bh', (4 * H,))
+    dp.add('Wz_h', (4, H + 1, Z)); dp.add('Wz_x', (4, H + 1, Z)); dp.add('Wz_b', (4, H, Z))
+    dp.add('Wzh', (4, Z, N)); dp.add('Wzx', (4, Z, N)); dp.add('Wzb', (4, Z, N)); dp.add('b0', (4, N))
+    dp.add('Wh', (N, 4 * N)); dp.add('Wx', (D, 4 * N))
+    # reference add_param order: hyper_lhuc_layers.py:251-276
+    for g, gn in enumerate(G4):
+        dp.map('W_hhat_' + gn, 'Whh', 'gatecols', g); dp.map('W_xhat_' + gn, 'Wxh', 'gatecols', g)
+        dp.map('bhat_' + gn, 'bh', 'gatevec', g)
+    for g, gn in enumerate(G4):
+        dp.map('W_hhat_h_' + gn, 'Wz_h', 'aug_w', g); dp.map('b_hhat_h_' + gn, 'Wz_h', 'aug_b', g)
+        dp.map('W_hhat_x_' + gn, 'Wz_x', 'aug_w', g); dp.map('b_hhat_x_' + gn, 'Wz_x', 'aug_b', g)
+        dp.map('W_hhat_b_' + gn, 'Wz_b', 'index', g)
+    for g, gn in enumerate(G4):
+        dp.map('W_hz_' + gn, 'Wzh', 'index', g); dp.map('W_xz_' + gn, 'Wzx', 'index', g)
+        dp.map('W_bz_' + gn, 'Wzb', 'index', g); dp.map('b_0_' + gn, 'b0', 'index', g)
+    for g, gn in enumerate(G4):
+        dp.map('W_h_' + gn, 'Wh', 'gatecols', g); dp.map('W_x_' + gn, 'Wx', 'gatecols', g)
+    return dp
+
+
+def perm4(src, dst, rows, N, inverse=False):
+    check(_lib.lib().asr_perm4(src.data_ptr(), dst.data_ptr(), rows, N, 1 if inverse else 0,
+                               torch.cuda.current_stream().cuda_stream), 'asr_perm4')
+    return dst
+
+
+class HyperPair(object):
+    kind = 'hyper'
+    stateful = False
+
+    def __init__(self, net, idx, D, N, H, Z, clip, ndir):
+        self.net = net; self.idx = idx
+        self.D, self.N, self.H, self.Z = D, N, H, Z
+        self.clip = float(clip); self.ndir = ndir
+        self.out_dim = ndir * N
+        self.dirs = [_mk_hyper(net.store, 'L%d.%d.' % (idx, d), D, N, H, Z) for d in range(ndir)]
+        self.reverse = [False, True][:ndir]
+
+    def describe(self):
+        out = {}
+        for d, nm in enumerate(('fwd', 'bwd')):
+            if d >= self.ndir:
+                out[nm] = None
+                continue
+            out[nm] = dict(kind='hyper',
+                           args=dict(num_units=self.N, num_hyper_units=self.H, num_proj_units=self.Z,
+                                     grad_clipping=self.clip, backwards=self.reverse[d]),
+                           params=[r[0] for r in self.dirs[d].refmap])
+        return out
+
+    def _buf(self, name, rows, cols):
+        return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols)
+
+    def _fold(self, dp, d):
+        """M (H+1, 12N) interleaved = [W_hhat_t ; b_t] . W_tz per gate  (eq.11 into eq.12)."""
+        N, H = self.N, self.H
+        Mg = self._buf('Mg%d' % d, H + 1, 12 * N).view(H + 1, 3, 4, N)
+        for tau, (wz, wzz) in enumerate((('Wz_h', 'Wzh'), ('Wz_x', 'Wzx'))):
+            for g in range(4):
+                ops.gemm(dp.p(wz)[g], dp.p(wzz)[g], Mg[:, tau, g, :])
+        for g in range(4):
+            ops.gemm(dp.p('Wz_b')[g], dp.p('Wzb')[g], Mg[:H, 2, g, :])
+        Mg[H, 2].copy_(dp.p('b0'))
+        Mi = self._buf('Mi%d' % d, H + 1, 12 * N)
+        perm4(Mg, Mi, (H + 1) * 3, N)
+        return Mi
+
+    def forward(self, X, T, B, mask, cond, train):
+        net = self.net; N, H = self.N, self.H
+        rows = T * B
+        L = _lib.lib()
+        Y = self._buf('Y', rows, self.out_dim)
+        desc = _lib.HyperScanDesc()
+        desc.T, desc.B, desc.N, desc.H, desc.ndir = T, B, N, H, self.ndir
+        desc.grad_clip = self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[])
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            c['xproj'] = ops.gemm(X, dp.p('Wx'), self._buf('xproj%d' % d, rows, 4 * N))
+            c['xhproj'] = ops.gemm(X, dp.p('Wxh')[N:], self._buf('xhproj%d' % d, rows, 4 * H), bias=dp.p('bh'))
+            Mi = self._fold(dp, d)
+            c['Mi'] = Mi
+            for mode, nm in ((0, 'wpk'), (1, 'wpkb')):
+                if mode == 1 and not train:
+                    continue
+                n = L.asr_hyper_pack_floats(N, H, mode)
+                out = net.arena.get('L%d.%s%d' % (self.idx, nm, d), n)
+                check(L.asr_hyper_pack_w(dp.p('Wh').data_ptr(), dp.p('Wxh').data_ptr(), dp.p('Whh').data_ptr(),
+                                         Mi.data_ptr(), N, H, mode, out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), 'asr_hyper_pack_w')
+                c[nm] = out
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            Dd.xproj = c['xproj'].data_ptr(); Dd.xhproj = c['xhproj'].data_ptr()
+            Dd.wpack = c['wpk'].data_ptr(); Dd.cvec = Mi[H].data_ptr()
+            R = Y[:, d * N:(d + 1) * N]
+            c['R'] = R
+            Dd.r_out = R.data_ptr(); Dd.ld_r = R.stride(0)
+            c['Hh'] = self._buf('Hh%d' % d, rows, H); Dd.hh_out = c['Hh'].data_ptr()
+            if train:
+                c['gates'] = self._buf('gates%d' % d, rows, 4 * N); Dd.gates = c['gates'].data_ptr()
+                c['cst'] = self._buf('cst%d' % d, rows, N); Dd.cst = c['cst'].data_ptr()
+                c['hgates'] = self._buf('hgates%d' % d, rows, 4 * H); Dd.hgates = c['hgates'].data_ptr()
+                c['hcst'] = self._buf('hcst%d' % d, rows, H); Dd.hcst = c['hcst'].data_ptr()
+                c['aD'] = self._buf('aD%d' % d, rows, 12 * N); Dd.aD = c['aD'].data_ptr()
+            ctx['d'].append(c)
+        net.scan_hyper(self, desc, backward=False)
+        return Y
+
+    def backward(self, dY, need_dx=True):
+        net = self.net; ctx = self.ctx; N, H, Z = self.N, self.H, self.Z
+        X, T, B, mask = ctx['X'], ctx['T'], ctx['B'], ctx['mask']
+        rows = T * B
+        desc = _lib.HyperScanDesc()
+        desc.T, desc.B, desc.N, desc.H, desc.ndir = T, B, N, H, self.ndir
+        desc.grad_clip = self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            Dd.xproj = c['xproj'].data_ptr(); Dd.wpack = c['wpkb'].data_ptr()
+            for nm in ('gates', 'cst', 'hgates', 'hcst', 'aD'):
+                setattr(Dd, nm, c[nm].data_ptr())
+            dR = dY[:, d * N:(d + 1) * N]
+            Dd.dr_ext = dR.data_ptr(); Dd.ld_dr = dR.stride(0)
+            c['dXp'] = self._buf('dXp%d' % d, rows, 4 * N); Dd.dXp = c['dXp'].data_ptr()
+            c['dXh'] = self._buf('dXh%d' % d, rows, 4 * H); Dd.dXh = c['dXh'].data_ptr()
+            c['dA'] = self._buf('dA%d' % d, rows, 4 * N); Dd.dA = c['dA'].data_ptr()
+            c['dD'] = self._buf('dD%d' % d, rows, 12 * N); Dd.dD = c['dD'].data_ptr()
+        net.scan_hyper(self, desc, backward=True)
+        dX = self._buf('dX', rows, self.D) if need_dx else None
+        n1 = (T - 1) * B
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            R, Hh = c['R'], c['Hh']
+            dA, dXh, dXp, dD = c['dA'], c['dXh'], c['dXp'], c['dD']
+            if not self.reverse[d]:
+                sl_prev, sl_cur = slice(0, n1), slice(B, rows)
+            else:
+                sl_prev, sl_cur = slice(B, rows), slice(0, n1)
+            ops.gemm(R[sl_prev], dA[sl_cur], dp.g('Wh'), ta=True)             # dW_h
+            ops.gemm(X, dXp, dp.g('Wx'), ta=True)                             # dW_x
+            gWxh = dp.g('Wxh')
+            ops.gemm(R[sl_prev], dXh[sl_cur], gWxh[:N], ta=True)              # dW_xhat (h rows)
+            ops.gemm(X, dXh, gWxh[N:], ta=True)                               # dW_xhat (x rows)
+            ops.colreduce(dXh, dp.g('bh'), rows, 4 * H)
+            ops.gemm(Hh[sl_prev], dXh[sl_cur], dp.g('Whh'), ta=True)          # dW_hhat
+            dMi = self._buf('dMi%d' % d, H + 1, 12 * N)
+            ops.gemm(Hh, dD, dMi[:H], ta=True)
+            ops.colreduce(dD, dMi[H], rows, 12 * N)
+            dMg = self._buf('dMg%d' % d, H + 1, 12 * N)
+            perm4(dMi, dMg, (H + 1) * 3, N, inverse=True)
+            dMg = dMg.view(H + 1, 3, 4, N)
+            for tau, (wz, wzz) in enumerate((('Wz_h', 'Wzh'), ('Wz_x', 'Wzx'))):
+                for g in range(4):
+                    ops.gemm(dMg[:, tau, g, :], dp.p(wzz)[g], dp.g(wz)[g], tb=True)
+                    ops.gemm(dp.p(wz)[g], dMg[:, tau, g, :], dp.g(wzz)[g], ta=True)
+            for g in range(4):
+                ops.gemm(dMg[:H, 2, g, :], dp.p('Wzb')[g], dp.g('Wz_b')[g], tb=True)
+                ops.gemm(dp.p('Wz_b')[g], dMg[:H, 2, g, :], dp.g('Wzb')[g], ta=True)
+            dp.g('b0').copy_(dMg[H, 2])
+            if need_dx:
+                ops.gemm(dXp, dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+                ops.gemm(dXh, dp.p('Wxh')[N:], dX, tb=True, beta=1.0)
+        return dX

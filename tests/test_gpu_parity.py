@@ -168,6 +168,27 @@ def test_tbptt_windows_carry_state():
             assert np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax) < 1e-4
 
 
+@pytest.mark.parametrize('is_bidir', [False, True])
+@pytest.mark.parametrize('clip', [0.0, 0.05])
+def test_hyperlstm_small(is_bidir, clip):
+    from asr_amd.builders import build_deep_hyperlstm
+    net = build_deep_hyperlstm('hyper', None, None, 5, 2, 8, 4, 2, 6, clip, is_bidir, 0,
+                               device=_dev(), seed=7)
+    perturb_params(net, 15, 0.15)
+    b = make_batch(np.random.default_rng(16), 3, 7, 5, 6)
+    run_case(net, b)
+
+
+def test_hyperlstm_medium():
+    """N=64, H=16, Z=8: 16 workgroups per direction, 1 hyper unit per workgroup, B=18 > 16."""
+    from asr_amd.builders import build_deep_hyperlstm
+    net = build_deep_hyperlstm('hyper', None, None, 11, 2, 64, 16, 8, 13, 1.0, True, 0,
+                               device=_dev(), seed=8)
+    perturb_params(net, 17, 0.03)
+    b = make_batch(np.random.default_rng(18), 18, 31, 11, 13)
+    run_case(net, b)
+
+
 def test_adam_step_matches_oracle():
     from asr_amd.builders import build_deep_lstm
     net = build_deep_lstm(None, None, 5, 1, 8, 0, 6, 0.0, False, False, 0, device=_dev(), seed=1)
