@@ -1,0 +1,45 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, torch.distributed with the
+"nccl" backend (= RCCL over xGMI on ROCm).  The reference has no distributed code; the
+only exchange step of the path is the SUM all-reduce of the flat fp32 gradient, bucketed per layer
+in reverse topological order and launched on a side stream as soon as that layer's BPTT has produced
+its gradients, so it overlaps with the BPTT of the layers below.  Batch rows never move."""
+import torch
+import torch.distributed as dist
+
+
+class GradAllReduce(object):
+    def __init__(self, net, group=None):
+        self.net = net
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        net.world = self.world
+        self.cuda = net.device.type == 'cuda'
+        self.stream = torch.cuda.Stream(device=net.device) if self.cuda else None
+        self.pending = []
+        if self.world > 1:
+            net.grad_hook = self.bucket_ready
+
+    def bucket_ready(self, lo, hi):
+        g = self.net.store.g[lo:hi]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()                           # gradients of this bucket are enqueued on main
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Before the optimiser step: make the main stream wait for every bucket."""
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    def reduce_scalars(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t

@@ -492,6 +492,9 @@ class Network(object):
         self.output_mode = 'softmax'      # what ff_fn returns: 'softmax' probabilities or 'logits'
         self._ws = {}
         self.finalized = False
+        self.world = 1               # data-parallel world size (loss normaliser = global batch)
+        self.grad_hook = None        # called as grad_hook(lo, hi) when flat grads [lo,hi) are final
+        self.scan_events = None      # list of (kind, backward, rows, ndir, ev0, ev1) when profiling
 
     # ---- construction -------------------------------------------------------------------------
     def add_pair(self, pair, spec_per_dir):
@@ -585,12 +588,28 @@ class Network(object):
             self._ws[key] = ws
         return ws
 
+    def param_range(self, prefix):
+        offs = [(off, off + (int(np.prod(shape)) + 3) // 4 * 4) for key, shape, off in self.store.entries
+                if key.startswith(prefix)]
+        return min(o[0] for o in offs), max(o[1] for o in offs)
+
+    def _timed(self, kind, backward, desc, call):
+        if self.scan_events is None:
+            return call()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = call()
+        e1.record()
+        self.scan_events.append((kind, bool(backward), desc.T * desc.B, desc.ndir, e0, e1))
+        return r
+
     def scan_lstm(self, pair, desc, backward):
         L = _lib.lib()
         need = L.asr_lstm_scan_ws_bytes(desc.T, desc.B, desc.N, desc.ndir, int(backward))
         ws = self._workspace(('lstm', pair.idx, backward), need)
         fn = L.asr_lstm_scan_bwd if backward else L.asr_lstm_scan_fwd
-        check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+        check(self._timed('lstm', backward, desc, lambda: fn(C.byref(desc), ws.data_ptr(), ws.numel(),
+                                                             torch.cuda.current_stream().cuda_stream)),
               'asr_lstm_scan_%s' % ('bwd' if backward else 'fwd'))
         self._last_groups = getattr(self, '_last_groups', {})
         self._last_groups[('lstm', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
@@ -600,7 +619,8 @@ class Network(object):
         need = L.asr_hyper_scan_ws_bytes(desc.T, desc.B, desc.N, desc.H, desc.ndir, int(backward))
         ws = self._workspace(('hyper', pair.idx, backward), need)
         fn = L.asr_hyper_scan_bwd if backward else L.asr_hyper_scan_fwd
-        check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+        check(self._timed('hyper', backward, desc, lambda: fn(C.byref(desc), ws.data_ptr(), ws.numel(),
+                                                              torch.cuda.current_stream().cuda_stream)),
               'asr_hyper_scan_%s' % ('bwd' if backward else 'fwd'))
         self._last_groups = getattr(self, '_last_groups', {})
         self._last_groups[('hyper', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
@@ -666,7 +686,7 @@ class Network(object):
         dl = self.arena.mat('dlogits', rows, self.C) if train else None
         row_ce = self.arena.get('row_ce', rows); row_ok = self.arena.get('row_ok', rows)
         pred = torch.empty(B, T, dtype=torch.int32, device=self.device)
-        ops.softmax_ce(logits, self.C, B, T, target=target, tmask=tm, scale=1.0 / B, dlogits=dl,
+        ops.softmax_ce(logits, self.C, B, T, target=target, tmask=tm, scale=1.0 / (B * self.world), dlogits=dl,
                        row_ce=row_ce, row_ok=row_ok, pred=pred)
         ops.reduce_sum(row_ce, rows, self.scal[0:1])
         ops.reduce_sum(row_ok, rows, self.scal[1:2])
@@ -682,8 +702,12 @@ class Network(object):
         ops.colreduce(dl, self.out.g('b'), dl.shape[0], self.C)
         dY = self.arena.mat('dtop', dl.shape[0], self.K_top)
         ops.gemm(dl, self.out.p('W'), dY, tb=True)
+        if self.grad_hook:
+            self.grad_hook(*self.param_range('out.'))
         for i in range(len(self.pairs) - 1, -1, -1):
             dY = self.pairs[i].backward(dY, need_dx=(i > 0))
+            if self.grad_hook:
+                self.grad_hook(*self.param_range('L%d.' % i))
 
     def adam_update(self, lr, b1=0.9, b2=0.999, eps=1e-8, want_sqrt=True):
         """libs/lasagne_libs/updates.py:587-617 on the flat buffer + grads_norm

@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): training frames/sec of a 4x512 HyperLSTM (H=128, Z=64,
+bidirectional, C=3436, B=16 per GPU, two concatenated WSJ-shaped utterances per row, grad_clipping
+1.0) -- forward + BPTT + gradient all-reduce + Adam, data already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of the gradients)
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the persistent HyperLSTM
+BPTT scan), timed live with HIP events on the launch stream; `cpu_baseline` is the numpy oracle
+(fp32) timed on a bounded sample of the same workload on the host cores (N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_UNITS, N_HYPER, N_Z, N_LAYERS, N_OUT, N_IN, BATCH = 512, 128, 64, 4, 3436, 123, 16
+
+
+def scan_bytes_per_row_dir(backward):
+    """Algorithmic HBM bytes per (t,b) row and direction of the HyperLSTM scan, fp32."""
+    N, H = N_UNITS, N_HYPER
+    if not backward:   # read xproj, xhproj; write h, hhat, gates, c, hgates, hc, (a, d_h, d_x)
+        words = 4 * N + 4 * H + N + H + 4 * N + N + 4 * H + H + 12 * N
+    else:              # read gates, c(t), c(t-1), (a,d_h,d_x), xproj, hgates, hc(t), hc(t-1), dh_ext
+        words = 4 * N + 2 * N + 12 * N + 4 * N + 4 * H + 2 * H + N
+        words += 4 * N + 4 * H + 4 * N + 12 * N          # write dXp, dXh, dA, dD
+    return 4 * words
+
+
+def cpu_baseline(net, sample_len=160):
+    """Oracle (numpy fp32, host BLAS threads) fwd + BPTT + Adam on a bounded sample: the same batch
+    truncated to `sample_len` frames per row."""
+    from oracle import asr_oracle as O
+    from asr_amd import workloads
+    b = workloads.make_batch(3, BATCH, 0, max_len=sample_len)
+    vals = net.get_all_param_values()
+    onet = O.OracleNetwork(net.describe(), vals, dtype=np.float32)
+    m = [np.zeros_like(v) for v in onet.values]; v = [np.zeros_like(x) for x in onet.values]
+    t0 = time.time()
+    _, _, _, grads = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    O.adam_step(onet.values, grads, m, v, 0)
+    dt = time.time() - t0
+    try:
+        import threadpoolctl
+        cores = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        cores = 1
+    return dict(value=b['frames'] / dt, unit='frames/s', cores=int(cores), kind='port',
+                sample='numpy fp32 oracle, 1 step fwd+BPTT+Adam, B=%d rows truncated to %d frames '
+                       '(%d frames, %.1f s)' % (BATCH, sample_len, b['frames'], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pool', type=int, default=4, help='distinct synthetic batches per rank')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = 'cuda:%d' % local
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from asr_amd.builders import build_deep_hyperlstm
+    from asr_amd import workloads, dp
+
+    net = build_deep_hyperlstm('hyper', None, None, N_IN, N_LAYERS, N_UNITS, N_HYPER, N_Z, N_OUT, 1.0,
+                               True, 0, device=dev, seed=1234)
+    ar = dp.GradAllReduce(net)
+    batches = []
+    for i in range(args.pool):
+        b = workloads.make_batch(3, BATCH, seed_offset=1000 * rank + i)
+        batches.append((torch.from_numpy(b['x']).to(dev), torch.from_numpy(b['mask']).to(dev),
+                        torch.from_numpy(b['y']).to(dev), b['frames'], b['x'].shape[1]))
+
+    def step(i):
+        x, m, y, frames, T = batches[i % len(batches)]
+        net.loss(x, m, y, m)
+        net.backward()
+        ar.finish()
+        net.adam_update(1e-3)
+        return frames
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    net.check_status()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    net.scan_events = []
+    t0 = time.time()
+    frames = 0
+    for i in range(args.steps):
+        frames += step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    net.check_status()
+    tt = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        fsum = tt[1:2].clone(); dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
+        dt = tmax.item(); frames = fsum.item()
+
+    if rank == 0:
+        ev = net.scan_events
+        net.scan_events = None
+        bwd = [(rows, ndir, e0.elapsed_time(e1)) for k, bw, rows, ndir, e0, e1 in ev if k == 'hyper' and bw]
+        fwd = [(rows, ndir, e0.elapsed_time(e1)) for k, bw, rows, ndir, e0, e1 in ev if k == 'hyper' and not bw]
+        ms = float(np.mean([t for _, _, t in bwd]))
+        byts = float(np.mean([rows * ndir * scan_bytes_per_row_dir(True) for rows, ndir, _ in bwd]))
+        steps_per_launch = float(np.mean([rows / BATCH for rows, _, _ in bwd]))
+        ach = byts / (ms * 1e-3) / 1e9
+        roof = dict(bound='hbm', kernel='hyper_scan_bwd_kernel', achieved=ach, peak=8000.0, unit='GB/s',
+                    frac=ach / 8000.0, traffic=None, avg_launch_ms=ms,
+                    us_per_timestep=ms * 1e3 / steps_per_launch,
+                    fwd_kernel_avg_launch_ms=float(np.mean([t for _, _, t in fwd])),
+                    scan_share_of_step=float(sum(t for _, _, t in bwd + fwd)) / (dt * 1e3))
+        out = dict(metric='train frames/sec (node) 4x512 HyperLSTM', value=frames / dt, unit='frames/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='cfg3: 4x512 HyperLSTM (H=128,Z=64) bidirectional, C=3436, '
+                                        'two concatenated WSJ-shaped utterances per row, fwd+BPTT+'
+                                        'all-reduce+Adam', per_gpu_batch=BATCH, global_batch=BATCH * world,
+                               parallelism='dp%d' % world),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(net)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
