@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libasr_amd.so')
+LIB_PATH = os.environ.get('ASR_AMD_LIB') or os.path.join(_HERE, 'libasr_amd.so')
 
 ERR = {0: 'ASR_OK', -1: 'ASR_ERR_ARG', -2: 'ASR_ERR_LAUNCH', -3: 'ASR_ERR_WS', -4: 'ASR_ERR_TIMEOUT'}
 
@@ -41,6 +41,7 @@ class HyperScanDesc(C.Structure):
 
 _SIGS = {
     'asr_gemm_f32': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp]),
+    'asr_gemm_f32_ws': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
     'asr_swap01': (i32, [fp, fp, i32, i32, i32, i32, i32, fp]),
     'asr_ln_rows_fwd': (i32, [fp, i32, i32, fp, i32, fp, fp, i32, fp, fp, fp, fp, fp]),
     'asr_ln_rows_bwd': (i32, [fp, i32, i32, fp, fp, fp, i32, fp, fp]),

@@ -13,8 +13,13 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, stamps=False):
+    """stamps=True builds the diagnostic libasr_amd_stamps.so (in-kernel phase stamps; select it with
+    ASR_AMD_LIB=...); never used by tests or bench numbers."""
+    global LIB
     srcs = sources()
+    if stamps:
+        return _build_stamps(srcs)
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in deps):
         return LIB
@@ -38,5 +43,16 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def _build_stamps(srcs):
+    lib = os.path.join(HERE, 'libasr_amd_stamps.so')
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-value',
+           '-DSCAN_STAMPS', '-shared', '-o', lib] + srcs
+    subprocess.check_call(cmd)
+    return lib
+
+
 if __name__ == '__main__':
+    if '--stamps' in sys.argv:
+        print(build(stamps=True))
+        sys.exit(0)
     print(build(force='--force' in sys.argv))

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
                                                         const float* __restrict__ A, int lda,
                                                         const float* __restrict__ B, int ldb,
                                                         float beta, float* __restrict__ C, int ldc,
-                                                        const float* __restrict__ bias, int ntn) {
+                                                        const float* __restrict__ bias, int ntn,
+                                                        int kchunk, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDSP];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDSP];
 
@@ -87,13 +88,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         }
     };
 
-    const int nk = (K + BK - 1) / BK;
-    load_tiles(0);
+    // split-K: blockIdx.y owns k in [kbeg, kend); partial tiles go to `part` and are summed in a
+    // fixed order by gemm_splitk_reduce_kernel (deterministic, no atomics)
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int Ksave = K;
+    K = kend;                                  // loads beyond kend read as zero
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    load_tiles(kbeg);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
         const int lr = lane & 31, lk = lane >> 5;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 2) {
@@ -112,6 +119,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         __syncthreads();
     }
 
+    K = Ksave;
+    if (part) {
+        float* P = part + (size_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (col >= N) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (row < M) P[(size_t)row * N + col] = acc[i][j][e];
+                }
+            }
+        return;
+    }
     // epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -133,22 +157,71 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         }
 }
 
-extern "C" int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A,
-                            int lda, const float* B, int ldb, float beta, float* C, int ldc,
-                            const float* bias, hipStream_t stream) {
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ns,
+                                                                  int M, int N, float alpha, float beta,
+                                                                  float* __restrict__ C, int ldc,
+                                                                  const float* __restrict__ bias) {
+    const size_t tot = (size_t)M * N;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int s = 0; s < ns; ++s) acc += part[(size_t)s * tot + i];
+        const int row = (int)(i / N), col = (int)(i % N);
+        float* p = C + (size_t)row * ldc + col;
+        float v = alpha * acc + (bias ? bias[col] : 0.f);
+        if (beta != 0.f) v += beta * (*p);
+        *p = v;
+    }
+}
+
+// ws (optional): scratch for split-K partials.  Split-K is used when the output has too few tiles to
+// fill the chip and K is long (the weight-gradient contractions, K = T*B).
+extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                               int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                               const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (M < 0 || N < 0 || K < 0 || !C) return ASR_ERR_ARG;
     if (M == 0 || N == 0) return ASR_OK;
     if (K > 0 && (!A || !B)) return ASR_ERR_ARG;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-    dim3 grid(ntm * ntn), block(256);
+    const int tiles = ntm * ntn;
+    int ns = 1;
+    if (ws && tiles < 128 && K >= 2048) {
+        ns = (512 + tiles - 1) / tiles;
+        const int maxk = K / (BK * 8);                       // at least 8 K-tiles per split
+        if (ns > maxk) ns = maxk;
+        if (ns > 64) ns = 64;
+        const size_t cap = ws_bytes / ((size_t)M * N * sizeof(float));
+        if ((size_t)ns > cap) ns = (int)cap;
+        if (ns < 1) ns = 1;
+    }
+    int kchunk = K > 0 ? K : 1;
+    if (ns > 1) {
+        kchunk = (((K + ns - 1) / ns + BK - 1) / BK) * BK;
+        ns = (K + kchunk - 1) / kchunk;
+    }
+    float* part = ns > 1 ? ws : nullptr;
+    dim3 grid(tiles, ns), block(256);
 #define LAUNCH(TA_, TB_)                                                                         \
     hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, block, 0, stream, M, N, K, alpha, A, lda, \
-                       B, ldb, beta, C, ldc, bias, ntn)
+                       B, ldb, beta, C, ldc, bias, ntn, kchunk, part)
     if (!transA && !transB) LAUNCH(false, false);
     else if (!transA && transB) LAUNCH(false, true);
     else if (transA && !transB) LAUNCH(true, false);
     else LAUNCH(true, true);
 #undef LAUNCH
     ASR_CHECK_LAUNCH();
+    if (ns > 1) {
+        const size_t tot = (size_t)M * N;
+        const int g = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, stream, part, ns, M, N, alpha,
+                           beta, C, ldc, bias);
+        ASR_CHECK_LAUNCH();
+    }
     return ASR_OK;
+}
+
+extern "C" int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                            int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                            const float* bias, hipStream_t stream) {
+    return asr_gemm_f32_ws(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, nullptr, 0,
+                           stream);
 }

@@ -71,6 +71,14 @@ __device__ __forceinline__ void st_sc1_f4(__amdgpu_buffer_rsrc_t rs, unsigned by
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
 }
+// 4-byte sc1 load with a per-lane byte offset (VGPR, loop-invariant) and a wave-uniform byte offset
+// (SGPR): no per-load vector address arithmetic; out-of-range reads return 0 (buffer range check).
+__device__ __forceinline__ float ldb_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 16));
+}
+__device__ __forceinline__ f32x4 ldb_sc1_f4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16));
+}
 // two floats as ONE aligned 8-byte sc1 store / load
 __device__ __forceinline__ void st_sc1_f2(float* p, float a, float b) {
     unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
@@ -93,3 +101,17 @@ __device__ __forceinline__ float sum_q(float v) {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// ---- optional in-kernel phase stamps (diagnostic build only: -DSCAN_STAMPS; never in the product .so)
+#define STAMP_BYTES 65536
+#ifdef SCAN_STAMPS
+#define STAMP_DECL unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_prev; st_prev = n_; } while (0)
+#define STAMP_DUMP(ptr, wg) do { if (threadIdx.x == 0 && (ptr) && (wg) < 512) { \
+    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) (ptr)[(size_t)(wg) * 10 + i_] = st_acc[i_]; } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i) do { } while (0)
+#define STAMP_DUMP(ptr, wg) do { } while (0)
+#endif

