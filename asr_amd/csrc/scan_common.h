@@ -16,43 +16,63 @@
 
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 
-#define SYNC_STRIDE 32          // u32 words per group (128 B): [0] arrivals, [1] abort
-#define SCAN_DEADLINE_TICKS 2000000000ull   // 20 s of s_memrealtime (100 MHz)
+#define SYNC_SHARDS 16
+#define SYNC_STRIDE ((SYNC_SHARDS + 1) * 32)   // u32 words per group: 16 arrival shards (one 128-B
+                                               // line each) + the abort word on its own line
+#define SYNC_ABORT (SYNC_SHARDS * 32)
+#define SCAN_DEADLINE_TICKS 1000000000ull      // 10 s of s_memrealtime (100 MHz)
 
+// One arrival counter serialises G atomics at the memory side (~12 ns each: measured 2.1 us of a
+// 3.6 us exchange at G = 128, tools/ubench/xchg.hip); 16 shards cut the fan-in to G/16 per word.
 struct GroupSync {
-    unsigned* words;            // this group's sync line
+    unsigned* words;            // this group's sync block
     unsigned G;                 // workgroups in the group
     unsigned epoch;             // exchanges completed so far (uniform across the group)
+    unsigned my_shard;          // shard this workgroup arrives on
+    unsigned members;           // lane s < SYNC_SHARDS: number of workgroups arriving on shard s
     unsigned long long deadline;
     int* lds_flag;              // one LDS int for broadcasting the poll result
 };
+
+__device__ __forceinline__ void group_sync_init(GroupSync& gs, unsigned* words, unsigned G, unsigned wg,
+                                                int* lds_flag) {
+    gs.words = words; gs.G = G; gs.epoch = 0; gs.lds_flag = lds_flag;
+    gs.my_shard = wg % SYNC_SHARDS;
+    const unsigned lane = threadIdx.x & 63;
+    gs.members = lane < SYNC_SHARDS ? (G > lane ? (G - lane + SYNC_SHARDS - 1) / SYNC_SHARDS : 0) : 0;
+    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
+}
 
 __device__ __forceinline__ void group_publish(GroupSync& gs) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its sc1 stores
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(gs.words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(gs.words + gs.my_shard * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // returns false when the group aborted (timeout somewhere): caller must leave its loop
 __device__ __forceinline__ bool group_wait(GroupSync& gs) {
     gs.epoch += 1;
-    const unsigned target = gs.epoch * gs.G;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {                               // wave 0 polls: lane s watches shard s,
+        const unsigned lane = threadIdx.x;                // lane SYNC_SHARDS watches the abort word
+        const unsigned target = gs.epoch * gs.members;
         int good = 1;
         for (;;) {
-            unsigned long long v = __hip_atomic_load((unsigned long long*)gs.words, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32)) { good = 0; break; }
-            if ((unsigned)v >= target) break;
+            unsigned v = 0;
+            if (lane <= SYNC_SHARDS) v = ld_sc1_u32(gs.words + lane * 32);
+            const bool arrived = lane < SYNC_SHARDS ? v >= target : true;
+            const bool aborted = (lane == SYNC_SHARDS) && v != 0;
+            if (__any(aborted)) { good = 0; break; }
+            if (__all(arrived)) break;
             if (__builtin_amdgcn_s_memrealtime() > gs.deadline) {
-                __hip_atomic_store(gs.words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0)
+                    __hip_atomic_store(gs.words + SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 good = 0;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        *gs.lds_flag = good;
+        if (lane == 0) *gs.lds_flag = good;
     }
     __syncthreads();
     const int ok = *gs.lds_flag;

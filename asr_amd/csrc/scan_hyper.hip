@@ -12,6 +12,7 @@
 // Group = G = N/4 workgroups; workgroup j owns main units 4j..4j+3 and hyper units j*UH..j*UH+UH-1.
 // Per step two exchanges: hhat_t (after the hyper cell) and h_t (after the main cell).
 #include "scan_common.h"
+#include <stdlib.h>
 
 struct HyperDir {
     int reverse;
@@ -35,7 +36,7 @@ struct HyperDir {
 
 struct HyperArgs {
     int T, B, N, H, G, UH, KS, KSP, KT, HS, HSP, HT;
-    int ndir, chunk0;
+    int ndir, chunk0, rpc;       // rpc = batch rows per chunk/group (8 or 16)
     float clip;
     const float* mask; int msb, mst;
     HyperDir d[2];
@@ -178,14 +179,11 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
     const HyperDir& D = A.d[dir];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, bl = lane & 15;
-    const int b = chunk * 16 + bl;
-    const bool bvalid = b < B;
+    const int b = chunk * A.rpc + bl;
+    const bool bvalid = (bl < A.rpc) && (b < B);
 
     GroupSync gs;
-    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
-    gs.G = G; gs.epoch = 0;
-    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
-    gs.lds_flag = flag;
+    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * per_wg);
         f32x4* dst = (f32x4*)smem;
@@ -386,14 +384,11 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     const HyperDir& D = A.d[dir];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, bl = lane & 15;
-    const int b = chunk * 16 + bl;
-    const bool bvalid = b < B;
+    const int b = chunk * A.rpc + bl;
+    const bool bvalid = (bl < A.rpc) && (b < B);
 
     GroupSync gs;
-    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
-    gs.G = G; gs.epoch = 0;
-    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
-    gs.lds_flag = flag;
+    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * per_wg);
         f32x4* dst = (f32x4*)smem;
@@ -662,7 +657,7 @@ extern "C" size_t asr_hyper_scan_ws_bytes(int T, int B, int N, int H, int ndir, 
     (void)T;
     HyperArgs A;
     hyper_dims(N, H, &A);
-    const size_t ng = (size_t)ndir * ((B + 15) / 16);
+    const size_t ng = (size_t)ndir * ((B + 7) / 8);     // sized for the 8-row chunking
     size_t bytes = ng * SYNC_STRIDE * 4;
     bytes += ng * 2 * A.KS * 64 * 4 + ng * 2 * A.G * 64 * 4;
     if (backward) {
@@ -695,8 +690,20 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     A.T = d->T; A.B = d->B; A.ndir = d->ndir; A.clip = d->grad_clip;
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
     A.d[0] = d->dir[0]; A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
-    const int nchunk = (d->B + 15) / 16;
-    const size_t ng = (size_t)d->ndir * nchunk;
+    const size_t per_wg = hyper_pack_floats_wg(A, backward);
+    size_t lds;
+    if (!backward) lds = (per_wg + 3 * 4 * 256) * 4 + 64;
+    else lds = (per_wg + 256 + 768 + 1024 + 256 + 1024) * 4 + 64;
+    if (lds > 160 * 1024) return ASR_ERR_ARG;
+    // Two workgroups fit one CU when each needs <= 80 KB of LDS.  Cutting the batch into 8-row chunks
+    // (two independent recurrences sharing a CU) was measured SLOWER (482 vs 325 ms/step on cfg3: the
+    // exchange is bound by memory-side traffic, which doubles), so it stays an experiment knob.
+    const int cap = (lds <= 80 * 1024) ? 512 : 256;
+    int rpc = 16;
+    if (const char* e = getenv("ASR_SCAN_RPC")) { const int v = atoi(e); if (v == 8 || v == 16) rpc = v; }
+    A.rpc = rpc;
+    const int nchunk = (d->B + rpc - 1) / rpc;
+    const size_t ng = (size_t)d->ndir * ((d->B + 7) / 8);
     char* p = (char*)ws;
     A.sync = (unsigned*)p;  p += ng * SYNC_STRIDE * 4;
     A.rex = (float*)p;      p += ng * 2 * A.KS * 64 * 4;
@@ -709,12 +716,8 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     }
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
     A.dbg = (unsigned long long*)((char*)ws + asr_hyper_scan_ws_bytes(d->T, d->B, d->N, d->H, d->ndir, backward) - STAMP_BYTES);
-    const size_t per_wg = hyper_pack_floats_wg(A, backward);
-    size_t lds;
-    if (!backward) lds = (per_wg + 3 * 4 * 256) * 4 + 64;
-    else lds = (per_wg + 256 + 768 + 1024 + 256 + 1024) * 4 + 64;
-    if (lds > 160 * 1024) return ASR_ERR_ARG;
-    int cpl = 256 / (A.G * d->ndir);
+    int cpl = cap / (A.G * d->ndir);
+    if (cpl < 1) cpl = 1;
     if (cpl > nchunk) cpl = nchunk;
     for (int c0 = 0; c0 < nchunk; c0 += cpl) {
         const int nc = nchunk - c0 < cpl ? nchunk - c0 : cpl;

@@ -164,10 +164,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     const int N = A.N, KS = A.KS, KSP = A.KSP, T = A.T, B = A.B;
 
     GroupSync gs;
-    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
-    gs.G = A.G; gs.epoch = 0;
-    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
-    gs.lds_flag = flag;
+    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
 
     // resident weights
     {
@@ -339,10 +336,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
     const int N = A.N, KS = A.KS, KT = A.KT, T = A.T, B = A.B, G = A.G;
 
     GroupSync gs;
-    gs.words = A.sync + (size_t)grp * SYNC_STRIDE;
-    gs.G = A.G; gs.epoch = 0;
-    gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
-    gs.lds_flag = flag;
+    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * UT * KT * 256);
         f32x4* dst = (f32x4*)Wb;
@@ -618,7 +612,7 @@ extern "C" int asr_scan_status(const void* ws, int ngroups) {
         rc = ASR_ERR_LAUNCH;
     else
         for (int g = 0; g < ngroups; ++g)
-            if (host[(size_t)g * SYNC_STRIDE + 1]) rc = ASR_ERR_TIMEOUT;
+            if (host[(size_t)g * SYNC_STRIDE + SYNC_ABORT]) rc = ASR_ERR_TIMEOUT;
     free(host);
     return rc;
 }

@@ -623,7 +623,7 @@ class Network(object):
                                                               torch.cuda.current_stream().cuda_stream)),
               'asr_hyper_scan_%s' % ('bwd' if backward else 'fwd'))
         self._last_groups = getattr(self, '_last_groups', {})
-        self._last_groups[('hyper', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
+        self._last_groups[('hyper', pair.idx, backward)] = desc.ndir * ((desc.B + 7) // 8)
 
     def check_status(self):
         """Call after a host sync: raises if any persistent scan gave up on a bounded wait."""
