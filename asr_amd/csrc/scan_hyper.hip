@@ -228,35 +228,58 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         if (!group_wait(gs)) break;
         STAMP(0);
 
-        // ---- phase 1: a = h.W_h (main tile) and hyper gate pre-activations, K split over waves
+        // ---- phase 1: hyper gate pre-activations first (they gate the first exchange); the main
+        // tile a = h.W_h is not needed before phase 2, so when the wave's whole K share of h fits one
+        // register chunk (N <= 512) its MFMAs are deferred until after the hhat publish and run
+        // under the exchange latency.  All B operands of a chunk are requested before the first
+        // MFMA so the exchange-buffer latency is paid once per chunk, not once per k-step.
         f32x4 am0 = {0, 0, 0, 0}, am1 = {0, 0, 0, 0}, ag0 = {0, 0, 0, 0}, ag1 = {0, 0, 0, 0};
         const int ic = (bl < CR ? bl : CR - 1);
-        // All B operands of a chunk are requested before the first MFMA so that the exchange-buffer
-        // latency is paid once per chunk, not once per k-step.
-        for (int h0 = 0; h0 < hs4; h0 += 4) {
-            float bh[16];
+        const bool defer = (ks4 <= 8);
+        float bh[16], bv[32];
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)(par * G * 256) + (unsigned)((wv * hs4 + h0) * 4 + i) * hh_sc);
-            if (h0 == 0) {
-                for (int c0 = 0; c0 < ks4; c0 += 8) {
-                    float bv[32];
+        for (int i = 0; i < 16; ++i)
+            bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)(par * G * 256) + (unsigned)((wv * hs4) * 4 + i) * hh_sc);
 #pragma unroll
-                    for (int i = 0; i < 32; ++i)
-                        bv[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * ks4 + c0) * 4 + i) * 256u);
+        for (int i = 0; i < 32; ++i)
+            bv[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * ks4) * 4 + i) * 256u);
 #pragma unroll
-                    for (int g4 = 0; g4 < 8; ++g4) {
-                        if (c0 + g4 < ks4) {
-                            const int s4 = wave * ks4 + c0 + g4;
-                            const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
-                            const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
-                            am0 = mfma4(av[0], bv[g4 * 4 + 0], am0); ag0 = mfma4(gv[0], bv[g4 * 4 + 0], ag0);
-                            am1 = mfma4(av[1], bv[g4 * 4 + 1], am1); ag1 = mfma4(gv[1], bv[g4 * 4 + 1], ag1);
-                            am0 = mfma4(av[2], bv[g4 * 4 + 2], am0); ag0 = mfma4(gv[2], bv[g4 * 4 + 2], ag0);
-                            am1 = mfma4(av[3], bv[g4 * 4 + 3], am1); ag1 = mfma4(gv[3], bv[g4 * 4 + 3], ag1);
-                        }
-                    }
+        for (int g4 = 0; g4 < 8; ++g4) {
+            if (g4 < ks4) {
+                const int s4 = wave * ks4 + g4;
+                const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
+                ag0 = mfma4(gv[0], bv[g4 * 4 + 0], ag0); ag1 = mfma4(gv[1], bv[g4 * 4 + 1], ag1);
+                ag0 = mfma4(gv[2], bv[g4 * 4 + 2], ag0); ag1 = mfma4(gv[3], bv[g4 * 4 + 3], ag1);
+                if (!defer) {
+                    const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
+                    am0 = mfma4(av[0], bv[g4 * 4 + 0], am0); am1 = mfma4(av[1], bv[g4 * 4 + 1], am1);
+                    am0 = mfma4(av[2], bv[g4 * 4 + 2], am0); am1 = mfma4(av[3], bv[g4 * 4 + 3], am1);
                 }
+            }
+        }
+        for (int c0 = 8; c0 < ks4; c0 += 8) {           // N > 512: further chunks, main + hyper together
+            float bw[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                bw[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * ks4 + c0) * 4 + i) * 256u);
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                if (c0 + g4 < ks4) {
+                    const int s4 = wave * ks4 + c0 + g4;
+                    const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
+                    const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
+                    am0 = mfma4(av[0], bw[g4 * 4 + 0], am0); ag0 = mfma4(gv[0], bw[g4 * 4 + 0], ag0);
+                    am1 = mfma4(av[1], bw[g4 * 4 + 1], am1); ag1 = mfma4(gv[1], bw[g4 * 4 + 1], ag1);
+                    am0 = mfma4(av[2], bw[g4 * 4 + 2], am0); ag0 = mfma4(gv[2], bw[g4 * 4 + 2], ag0);
+                    am1 = mfma4(av[3], bw[g4 * 4 + 3], am1); ag1 = mfma4(gv[3], bw[g4 * 4 + 3], ag1);
+                }
+            }
+        }
+        for (int h0 = 0; h0 < hs4; h0 += 4) {
+            if (h0 > 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)(par * G * 256) + (unsigned)((wv * hs4 + h0) * 4 + i) * hh_sc);
             }
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -268,13 +291,13 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
                 }
             }
         }
-        *(f32x4*)(red + ((size_t)(0 * 4 + wave) * 64 + lane) * 4) = am0 + am1;
+        if (!defer) *(f32x4*)(red + ((size_t)(0 * 4 + wave) * 64 + lane) * 4) = am0 + am1;
         *(f32x4*)(red + ((size_t)(1 * 4 + wave) * 64 + lane) * 4) = ag0 + ag1;
         STAMP(1);
         __syncthreads();
         f32x4 a4 = {0, 0, 0, 0};
         f32x4 hsave = {0, 0, 0, 0};
-        if (wave == 0) {
+        if (wave == 0 && !defer) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(0 * 4 + w) * 64 + lane) * 4);
         }
@@ -292,6 +315,19 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         STAMP(2);
         group_publish(gs);
         STAMP(3);
+        if (defer) {                              // main tile under the exchange latency
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                if (g4 < ks4) {
+                    const f32x4 av = *(const f32x4*)(Wm + ((size_t)(wave * ks4 + g4) * 64 + lane) * 4);
+                    am0 = mfma4(av[0], bv[g4 * 4 + 0], am0); am1 = mfma4(av[1], bv[g4 * 4 + 1], am1);
+                    am0 = mfma4(av[2], bv[g4 * 4 + 2], am0); am1 = mfma4(av[3], bv[g4 * 4 + 3], am1);
+                }
+            }
+            // slot 0 is free here: its last reader (wave 0, previous step's main epilogue) has passed
+            // the publish barrier above
+            *(f32x4*)(red + ((size_t)(0 * 4 + wave) * 64 + lane) * 4) = am0 + am1;
+        }
         if (wave == 1 && bvalid && hvalid) {      // bulk saves after the publish: off the critical path
             D.hh_out[row * H + hu] = hh;
             if (D.hgates) {
@@ -301,6 +337,10 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         }
         if (!group_wait(gs)) break;
         STAMP(4);
+        if (wave == 0 && defer) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(0 * 4 + w) * 64 + lane) * 4);
+        }
 
         // ---- phase 2: d_h, d_x, bias = hhat_t . M  (3 tiles), then the main cell
         f32x4 ad[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -322,6 +362,7 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
                 }
             }
         }
+        __syncthreads();                          // wave 0 has taken a4 out of slot 0
 #pragma unroll
         for (int tau = 0; tau < 3; ++tau) *(f32x4*)(red + ((size_t)(tau * 4 + wave) * 64 + lane) * 4) = ad[tau];
         STAMP(5);
