@@ -1,0 +1,227 @@
+"""The compiled callables of libs/comp_graph_utils.py, same names / argument order / return lists:
+
+  trainer :68-100          training_fn(x, mask, [ivec,] y, ymask) -> [ce_frame_sum, grads_norm]
+  trainer_tbptt :102-137   training_fn(x, mask, [ivec,] y, ymask, is_first_win) -> [ce_frame_sum, grads_norm**2]
+  predictor :158-169       predict_fn(...)  -> [ce_frame_sum, pred_idx]
+  predictor_tbptt :139-156 predict_fn(..., is_first_win) -> [ce_frame_sum, pred_idx]
+  ff :321-333              ff_fn(x, mask[, ivec]) -> [posteriors (B,T,C)]
+  ff_tbptt :335-351        ff_fn(x, mask, [ivec,] is_first_win) -> [posteriors]
+  eval_net :171-198, eval_net_tbptt :278-319
+
+The reference builds these from Theano symbols; here the symbolic arguments (`input_data`, ... ) are
+placeholders that are only tested for truthiness (`ivector_data` switches the i-vector argument on),
+and the returned callables take numpy arrays (or cuda tensors), run the HIP path synchronously and
+return numpy scalars / arrays, as a `theano.function` does.  With torch.distributed initialised each
+rank feeds its own rows and the gradient all-reduce of asr_amd.dp runs inside training_fn.
+"""
+import numpy as np
+import torch
+
+from . import dp
+from .utils import gen_win
+
+
+def _dev(network, a, dtype=None):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        t = a.to(network.device)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(network.device)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t
+
+
+def _given(v):
+    return v is not None and v is not False
+
+
+def _split_args(args, has_ivec, n_tail):
+    """(x, mask, [ivec,] *tail) -> x, mask, ivec, tail"""
+    need = 2 + (1 if has_ivec else 0) + n_tail
+    if len(args) != need:
+        raise TypeError('expected %d positional inputs, got %d' % (need, len(args)))
+    x, mask = args[0], args[1]
+    ivec = args[2] if has_ivec else None
+    tail = args[need - n_tail:]
+    return x, mask, ivec, tail
+
+
+def _reducer(network):
+    r = getattr(network, '_grad_allreduce', None)
+    if r is None:
+        r = network._grad_allreduce = dp.GradAllReduce(network)
+    return r
+
+
+def _loss(network, args, has_ivec, train, delay=0, context=0, tbptt=False):
+    x, mask, ivec, tail = _split_args(args, has_ivec, 3 if tbptt else 2)
+    y, ymask = tail[0], tail[1]
+    is_first = int(tail[2]) if tbptt else 1
+    d = delay if (not tbptt or is_first) else 0          # delayed_tbptt: only on the first window
+    c = context if (tbptt and not delay) else 0          # `elif context` (:52-55)
+    f32 = torch.float32
+    return network.loss(_dev(network, x, f32), _dev(network, mask, f32), _dev(network, y, torch.int32),
+                        _dev(network, ymask, f32), cond=_dev(network, ivec, f32), train=train,
+                        context=c, delay=d)
+
+
+def trainer(input_data, input_mask, target_data, target_mask, network, updater, learning_rate, delay=0,
+            load_updater_params=None, ivector_data=None):
+    has_ivec = _given(ivector_data)
+    update, trainer_params = updater(loss_or_grads=None, params=network.get_all_params(trainable=True),
+                                     learning_rate=learning_rate, load_params_dict=load_updater_params)
+    red = _reducer(network)
+
+    def training_fn(*args):
+        ce, _, _ = _loss(network, args, has_ivec, True, delay=delay)
+        network.backward()
+        red.finish()
+        gn = update.apply(network, want_sqrt=True)
+        out = torch.cat([ce, gn]).cpu().numpy()
+        network.check_status()
+        return [np.float32(out[0]), np.float32(out[1])]
+
+    return training_fn, trainer_params
+
+
+def trainer_tbptt(input_data, input_mask, target_data, target_mask, network, updater, learning_rate,
+                  tbptt_layers, is_first_win, delay, context, load_updater_params=None, ivector_data=None):
+    has_ivec = _given(ivector_data)
+    update, trainer_params = updater(loss_or_grads=None, params=network.get_all_params(trainable=True),
+                                     learning_rate=learning_rate, load_params_dict=load_updater_params)
+    red = _reducer(network)
+
+    def training_fn(*args):
+        ce, _, _ = _loss(network, args, has_ivec, True, delay=delay, context=context, tbptt=True)
+        network.backward()
+        red.finish()
+        gn = update.apply(network, want_sqrt=False)          # un-rooted sum (:111)
+        out = torch.cat([ce, gn]).cpu().numpy()
+        network.check_status()
+        return [np.float32(out[0]), np.float32(out[1])]
+
+    return training_fn, trainer_params
+
+
+def predictor(input_data, input_mask, target_data, target_mask, network, delay=0, ivector_data=None):
+    has_ivec = _given(ivector_data)
+
+    def fn(*args):
+        ce, _, pred = _loss(network, args, has_ivec, False, delay=delay)
+        network.check_status()
+        return [np.float32(ce.item()), pred.cpu().numpy().astype(np.int64)]
+
+    return fn
+
+
+def predictor_tbptt(input_data, input_mask, target_data, target_mask, network, tbptt_layers, is_first_win,
+                    delay, context, ivector_data=None):
+    has_ivec = _given(ivector_data)
+
+    def fn(*args):
+        ce, _, pred = _loss(network, args, has_ivec, False, delay=delay, context=context, tbptt=True)
+        network.check_status()
+        return [np.float32(ce.item()), pred.cpu().numpy().astype(np.int64)]
+
+    return fn
+
+
+def ff(network, input_data, input_mask, ivector_data=None, log=False):
+    """`log=True` = the in-graph max-subtracted log-softmax of bin/forward_ln_lstmp.py:55-62."""
+    has_ivec = _given(ivector_data)
+
+    def predict_fn(*args):
+        x, mask, ivec, _ = _split_args(args, has_ivec, 0)
+        f32 = torch.float32
+        out = network.posteriors(_dev(network, x, f32), _dev(network, mask, f32),
+                                 cond=_dev(network, ivec, f32), log=log)
+        network.check_status()
+        return [out.cpu().numpy()]
+
+    return predict_fn
+
+
+def ff_cond(network, input_data, input_cond, input_mask, log=True):
+    """bin/forward_ivec_ln_lstmp.py:58-65: argument order (input_data, input_cond, input_mask)."""
+    def predict_fn(x, cond, mask):
+        f32 = torch.float32
+        out = network.posteriors(_dev(network, x, f32), _dev(network, mask, f32),
+                                 cond=_dev(network, cond, f32), log=log)
+        network.check_status()
+        return [out.cpu().numpy()]
+
+    return predict_fn
+
+
+def ff_tbptt(input_data, input_mask, network, is_first_win, delay, num_tbptt_steps, ivector_data=None):
+    has_ivec = _given(ivector_data)
+
+    def fn(*args):
+        x, mask, ivec, tail = _split_args(args, has_ivec, 1)
+        first = int(tail[0])
+        f32 = torch.float32
+        o = network.posteriors(_dev(network, x, f32), _dev(network, mask, f32), cond=_dev(network, ivec, f32))
+        network.check_status()
+        o = o.cpu().numpy()
+        if delay:
+            o = o[:, delay:, :] if first else o
+        elif num_tbptt_steps:
+            o = o[:, :num_tbptt_steps, :]
+        return [o]
+
+    return fn
+
+
+def eval_net(predict_fn, data_stream, use_ivectors=False, delay=0):
+    total_ce_sum = 0.
+    total_accuracy_sum = 0
+    total_frame_count = 0
+    for batch_cnt, data in enumerate(data_stream.get_epoch_iterator(), start=1):
+        input_data, input_mask, ivector_data, ivector_mask, target_data, target_mask = data
+        if use_ivectors:
+            predict_output = predict_fn(input_data, input_mask, ivector_data, target_data, target_mask)
+        else:
+            predict_output = predict_fn(input_data, input_mask, target_data, target_mask)
+        ce_frame_sum, pred_idx = predict_output
+        target_data, target_mask = target_data[:, delay:], target_mask[:, delay:]
+        match_data = (target_data == pred_idx) * target_mask
+        total_accuracy_sum += match_data.sum()
+        total_ce_sum += ce_frame_sum
+        total_frame_count += target_mask.sum()
+    avg_ce = total_ce_sum / total_frame_count
+    avg_fer = 1.0 - (total_accuracy_sum / total_frame_count)
+    return avg_ce, avg_fer
+
+
+def eval_net_tbptt(predict_fn, data_stream, tbptt_layers, num_tbptt_steps, batch_size, right_context,
+                   use_ivectors=False, delay=0):
+    total_accuracy_sum = 0
+    total_ce_sum = 0.
+    total_frame_count = 0
+    for b_idx, batch in enumerate(data_stream.get_epoch_iterator(), start=1):
+        i_data, _, _, _, t_data, t_mask = batch
+        n_batch = i_data.shape[0]
+        for l in tbptt_layers:
+            l.reset(n_batch)
+        pred_idx_list = []
+        for win_idx, win in enumerate(gen_win(batch, num_tbptt_steps, right_context), start=1):
+            input_data, input_mask, ivector_data, ivector_mask, target_data, target_mask = win
+            is_first_win = 1 if win_idx == 1 else 0
+            if use_ivectors:
+                predict_output = predict_fn(input_data, input_mask, ivector_data, target_data, target_mask,
+                                            is_first_win)
+            else:
+                predict_output = predict_fn(input_data, input_mask, target_data, target_mask, is_first_win)
+            ce_frame_sum, pred_idx = predict_output
+            total_ce_sum += ce_frame_sum
+            pred_idx_list.append(pred_idx)
+        target_data, target_mask = t_data[:, delay:], t_mask[:, delay:]
+        pred_idx = np.concatenate(pred_idx_list, axis=1)
+        match_data = (target_data == pred_idx) * target_mask
+        total_accuracy_sum += match_data.sum()
+        total_frame_count += target_mask.sum()
+    avg_ce = total_ce_sum / total_frame_count
+    avg_fer = 1.0 - (total_accuracy_sum / total_frame_count)
+    return avg_ce, avg_fer

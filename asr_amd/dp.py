@@ -43,3 +43,27 @@ class GradAllReduce(object):
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+
+def shard_rows(lengths, rank, world):
+    """Rows of the global batch that `rank` takes: the batch is sorted by length and dealt
+    in contiguous blocks of B/world rows, so the padded T of a rank is set by rows of similar length.
+    Returns the (sorted) row indices; every row goes to exactly one rank."""
+    import numpy as np
+    order = np.argsort(np.asarray(lengths), kind='stable')
+    B = len(order)
+    if B % world:
+        raise ValueError('global batch %d is not divisible by world size %d' % (B, world))
+    per = B // world
+    return order[rank * per:(rank + 1) * per]
+
+
+def shard_batch(batch, rank, world):
+    """batch: the reference's 6-tuple (or a test-time 4-tuple); arrays sliced to this rank's rows and
+    trimmed to the rank's own longest utterance."""
+    import numpy as np
+    mask = np.asarray(batch[1])
+    rows = shard_rows(mask.sum(axis=1), rank, world)
+    T = int(mask[rows].sum(axis=1).max()) if len(rows) else 0
+    T = max(T, 1)
+    return tuple(None if a is None else np.ascontiguousarray(np.asarray(a)[rows][:, :T]) for a in batch)

@@ -127,6 +127,22 @@ class DirParams(object):
             else:
                 self._view(E, kind, arg).copy_(v)
 
+    def ref_view(self, i, grads=False):
+        """The i-th reference parameter of this direction as a numpy array (a copy)."""
+        ref_name, name, kind, arg = self.refmap[i]
+        E = self.g(name) if grads else self.p(name)
+        v = _PermView(E).to_ref() if kind == 'perm4' else self._view(E, kind, arg)
+        return v.detach().contiguous().cpu().numpy()
+
+    def ref_set(self, i, value):
+        ref_name, name, kind, arg = self.refmap[i]
+        E = self.p(name)
+        v = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32)).to(E.device)
+        if kind == 'perm4':
+            _PermView(E).copy_from(v)
+        else:
+            self._view(E, kind, arg).copy_(v)
+
     def dump_ref(self, grads=False):
         out = []
         for ref_name, name, kind, arg in self.refmap:
@@ -134,6 +150,24 @@ class DirParams(object):
             v = _PermView(E).to_ref() if kind == 'perm4' else self._view(E, kind, arg)
             out.append((ref_name, v.detach().contiguous().cpu().numpy()))
         return out
+
+
+class ParamHandle(object):
+    """Stand-in for a Theano shared variable of the reference's parameter list."""
+    def __init__(self, dp, i):
+        self.dp = dp; self.i = i
+        self.name = dp.prefix + dp.refmap[i][0]
+
+    def get_value(self, borrow=False):
+        return self.dp.ref_view(self.i)
+
+    def set_value(self, value, borrow=False):
+        if tuple(np.shape(value)) != tuple(self.get_value().shape):
+            raise ValueError('shape mismatch for %s' % self.name)
+        self.dp.ref_set(self.i, value)
+
+    def __repr__(self):
+        return self.name
 
 
 def _mk_lstm_family(store, prefix, kind, D, N, P, use_ln, I=0, F=0, npu=0, npl=0):
@@ -544,6 +578,16 @@ class Network(object):
                 res.append((ref_name, tuple(v.shape)))
         return res
 
+    def get_all_params(self, trainable=True):
+        """= lasagne.layers.get_all_params(network, trainable=True): handles with the shared-variable
+        protocol the reference uses on them (.name, .get_value(), .set_value(v)), in the
+        reference's order."""
+        out = []
+        for dp in self._all_dirparams():
+            for i in range(len(dp.refmap)):
+                out.append(ParamHandle(dp, i))
+        return out
+
     def get_all_param_values(self, grads=False):
         """= lasagne.layers.get_all_param_values(network, trainable=True): list of numpy arrays in
         the reference's order (libs/utils.py:80-85 pickles exactly this list)."""
@@ -673,7 +717,7 @@ class Network(object):
             ops.softmax_ce(logits, self.C, B, T, out_mode=1 if log else 2, out=out)
         return out
 
-    def loss(self, x, mask, target, target_mask, cond=None, train=True, context=0):
+    def loss(self, x, mask, target, target_mask, cond=None, train=True, context=0, delay=0):
         """compute_loss (libs/comp_graph_utils.py:29-45) / compute_loss_tbptt (:47-66, context form).
         Leaves dlogits (scaled by 1/n_batch, libs/comp_graph_utils.py:40) ready for backward()."""
         logits = self.forward(x, mask, cond, train=train)
@@ -682,6 +726,8 @@ class Network(object):
         tm = target_mask.contiguous()
         if context and context < T:
             tm = tm.clone(); tm[:, context:] = 0
+        if delay:                                  # delayed(): o[:, delay:], libs/comp_graph_utils.py:18-24
+            tm = tm.clone(); tm[:, :delay] = 0
         target = target.contiguous()
         dl = self.arena.mat('dlogits', rows, self.C) if train else None
         row_ce = self.arena.get('row_ce', rows); row_ok = self.arena.get('row_ok', rows)
@@ -693,6 +739,8 @@ class Network(object):
         self.dlogits = dl
         if context and context < T:
             pred = pred[:, :context]
+        if delay:
+            pred = pred[:, delay:]
         return self.scal[0:1], self.scal[1:2], pred
 
     def backward(self):

@@ -128,6 +128,50 @@ int asr_lstm_scan_bwd(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, as
 /* after the stream is synchronised: ASR_ERR_TIMEOUT if any group's bounded wait expired */
 int asr_scan_status(const void* ws, int ngroups);
 
+/* (rows,4N) gate-major [i|f|c|o] <-> gate-interleaved col = unit*4+gate (dir 0: to interleaved,
+ * 1: back).  The concatenation of the reference's per-gate matrices, libs/lhuclstm_layers.py:58-60,
+ * libs/lasagne_libs/hyper_lhuc_layers.py:447-466, in the engine's column order. */
+int asr_perm4(const float* src, float* dst, int rows, int N, int dir, asr_stream_t stream);
+
+/* K2 (HyperLSTM).  Persistent scan forward and BPTT: theano.scan(step_masked) over
+ * [orig_input, input, mask] with states (hyper_c, hyper_h, c, h) and its gradient,
+ * libs/lasagne_libs/hyper_lhuc_layers.py:216-237 (eq.10), :363-412 (step), :414-425, :493-500.
+ * The caller hoists the x_t half of eq.10 (xhproj = x.W_xhat[N:] + bhat) and folds eq.11 into eq.12
+ * (M = [W_hhat_* ; b_*].W_*z, shape (H+1, 12N), gate-interleaved; row H = cvec). */
+typedef struct asr_hyper_dir {
+    int reverse;
+    const float* xproj;       /* (T,B,4N) x.W_x */
+    const float* xhproj;      /* (T,B,4H) */
+    const float* wpack;       /* asr_hyper_pack_w output (mode 0 for fwd, 1 for bwd) */
+    const float* cvec;        /* (12N) constant row of the folded matrix: [c_h | c_x | c_b] */
+    float* r_out; int ld_r;   /* (T,B,ld_r) h_t */
+    float* hh_out;            /* (T,B,H)  hhat_t */
+    float* gates;             /* (T,B,4N) saved for BPTT (NULL = inference) */
+    float* cst;               /* (T,B,N) */
+    float* hgates;            /* (T,B,4H) */
+    float* hcst;              /* (T,B,H) */
+    float* aD;                /* (T,B,3,4N): a = h_{t-1}.W_h, d_h, d_x */
+    const float* dr_ext; int ld_dr;   /* backward: dLoss/dh_t from above */
+    float* dXp;               /* (T,B,4N) dgates*d_x  -> dW_x, dx */
+    float* dXh;               /* (T,B,4H) hyper gate grads -> dW_xhat, dbhat, dW_hhat, dx */
+    float* dA;                /* (T,B,4N) dgates*d_h  -> dW_h */
+    float* dD;                /* (T,B,3,4N) [dgates*a, dgates*xproj, dgates] -> dM, dcvec */
+} asr_hyper_dir;
+
+typedef struct asr_hyper_scan_desc {
+    int T, B, N, H, ndir;
+    float grad_clip;
+    const float* mask; int mask_stride_b, mask_stride_t;
+    asr_hyper_dir dir[2];
+} asr_hyper_scan_desc;
+
+size_t asr_hyper_pack_floats(int N, int H, int mode);
+int asr_hyper_pack_w(const float* Wh, const float* Whx, const float* Whh, const float* M, int N, int H,
+                     int mode, float* out, asr_stream_t stream);
+size_t asr_hyper_scan_ws_bytes(int T, int B, int N, int H, int ndir, int backward);
+int asr_hyper_scan_fwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+int asr_hyper_scan_bwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

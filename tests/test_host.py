@@ -1,0 +1,308 @@
+"""CPU tests of the host side: C-ABI surface, Kaldi posterior files, pickles, TBPTT windowing, flags,
+batch streams, parameter inventories and the data-parallel helpers (gloo, world_size 2)."""
+import ctypes as C
+import io
+import os
+import pickle
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------
+# C-ABI: header <-> library <-> ctypes binding
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'asr_amd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(asr_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_declares_every_bound_symbol():
+    from asr_amd import _lib
+    assert _header_functions() == _lib.declared_symbols()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from asr_amd import _lib
+    L = _lib.lib()                       # resolves every symbol of _SIGS; no compute call
+    for name in _header_functions():
+        assert hasattr(L, name), name
+    # pure host helpers can be called without a GPU
+    assert L.asr_lstm_pack_floats(256, 0) > 0
+    assert L.asr_hyper_pack_floats(512, 128, 0) > 0
+    assert L.asr_hyper_scan_ws_bytes(100, 16, 512, 128, 2, 1) > L.asr_hyper_scan_ws_bytes(100, 16, 512, 128, 2, 0)
+    assert L.asr_colreduce_ws_bytes(2048, 0) > 0
+
+
+def test_header_is_plain_c_and_struct_layout_matches_ctypes(tmp_path):
+    from asr_amd import _lib
+    prog = tmp_path / 'layout.c'
+    prog.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "asr_amd.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\\n", sizeof(asr_lstm_dir), sizeof(asr_lstm_scan_desc), sizeof(asr_hyper_dir),
+         sizeof(asr_hyper_scan_desc));
+  printf("%zu %zu %zu %zu\\n", offsetof(asr_lstm_scan_desc, dir), offsetof(asr_lstm_dir, dOut),
+         offsetof(asr_hyper_scan_desc, dir), offsetof(asr_hyper_dir, dD));
+  return 0;
+}''')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                           str(prog), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    got = [int(v) for v in out]
+    want = [C.sizeof(_lib.LstmDir), C.sizeof(_lib.LstmScanDesc), C.sizeof(_lib.HyperDir),
+            C.sizeof(_lib.HyperScanDesc), _lib.LstmScanDesc.dir.offset, _lib.LstmDir.dOut.offset,
+            _lib.HyperScanDesc.dir.offset, _lib.HyperDir.dD.offset]
+    assert got == want
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['ASR_AMD_LIB'] = %r\n"
+            "from asr_amd import _lib\n"
+            "try:\n    _lib.lib()\nexcept RuntimeError as e:\n    print('LOUD', e)\n" % (ROOT, str(tmp_path / 'nope.so')))
+    out = subprocess.check_output([sys.executable, '-c', code]).decode()
+    assert 'LOUD' in out and 'no CPU fallback' in out
+
+
+# ------------------------------------------------------------------------------------------------
+# Kaldi posterior files
+def test_kaldi_ark_binary_layout_and_roundtrip(tmp_path):
+    from asr_amd import kaldi_io
+    rng = np.random.default_rng(0)
+    mats = [('utt_a', rng.standard_normal((5, 7)).astype(np.float32)),
+            ('utt_b', rng.standard_normal((1, 7)).astype(np.float32)),
+            ('utt_c', np.zeros((0, 7), dtype=np.float32))]
+    p = str(tmp_path / 'post.ark')
+    with kaldi_io.BaseFloatMatrixWriter('ark:' + p) as w:
+        for k, m in mats:
+            w.write(k.encode('ascii'), m)          # the reference passes uttid.encode('ascii')
+    raw = open(p, 'rb').read()
+    # byte-exact header of the first entry: key, space, \0B, FM, space, \4 rows, \4 cols
+    assert raw.startswith(b'utt_a \x00BFM \x04\x05\x00\x00\x00\x04\x07\x00\x00\x00')
+    assert raw[21:21 + 5 * 7 * 4] == mats[0][1].tobytes()
+    back = kaldi_io.read_mat_ark('ark:' + p)
+    assert [k for k, _ in back] == [k for k, _ in mats]
+    for (_, a), (_, b) in zip(back, mats):
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_kaldi_ark_scp_and_text(tmp_path):
+    from asr_amd import kaldi_io
+    rng = np.random.default_rng(1)
+    mats = [('u%d' % i, rng.standard_normal((i + 2, 3)).astype(np.float32)) for i in range(4)]
+    ark, scp, txt = (str(tmp_path / n) for n in ('a.ark', 'a.scp', 'a.txt'))
+    with kaldi_io.BaseFloatMatrixWriter('ark,scp:%s,%s' % (ark, scp)) as w:
+        for k, m in mats:
+            w.write(k, m)
+    back = kaldi_io.read_mat_ark('scp:' + scp)
+    assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(back, mats))
+    with kaldi_io.BaseFloatMatrixWriter('ark,t:' + txt) as w:
+        for k, m in mats:
+            w.write(k, m)
+    back = kaldi_io.read_mat_ark('ark:' + txt)
+    assert [k for k, _ in back] == [k for k, _ in mats]
+    assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(back, mats))   # repr() round-trips f32
+    with pytest.raises(ValueError):
+        kaldi_io.BaseFloatMatrixWriter('ark:' + ark).write('bad key', mats[0][1])
+    with pytest.raises(ValueError):
+        kaldi_io.BaseFloatMatrixWriter('ark:' + ark).write('k', np.zeros(3))
+
+
+# ------------------------------------------------------------------------------------------------
+# pickles / parameter lists
+class _FakeParam(object):
+    def __init__(self, v):
+        self.v = np.array(v, dtype=np.float32)
+
+    def get_value(self):
+        return self.v.copy()
+
+    def set_value(self, v):
+        self.v = np.array(v, dtype=np.float32)
+
+
+def test_model_pickle_layout_and_errors(tmp_path):
+    from asr_amd import utils
+    params = [_FakeParam(np.arange(6).reshape(2, 3)), _FakeParam(np.ones(4))]
+    p = str(tmp_path / 'm_last_model.pkl')
+    utils.save_network(params, {'t_prev': None}, 7, p)
+    obj = pickle.load(open(p, 'rb'))
+    assert isinstance(obj, list) and len(obj) == 3
+    assert obj[1] is None and obj[2] == 7                     # reference quirk: updater values are None
+    assert [a.shape for a in obj[0]] == [(2, 3), (4,)]
+    for q in params:
+        q.set_value(np.zeros_like(q.v))
+
+    class A(object):
+        reload_model = p
+    upd, epoch = utils.load_or_init_model(params, A())
+    assert upd is None and epoch == 7 and params[0].v[1, 2] == 5
+    with pytest.raises(ValueError, match='got 1 values to set 2 parameters'):
+        utils.set_model_param_value(params, [np.zeros((2, 3))])
+    with pytest.raises(ValueError, match='parameter has shape'):
+        utils.set_model_param_value(params, [np.zeros((2, 3)), np.zeros(5)])
+    assert params[0].v[1, 2] == 5                              # nothing was set on failure
+
+    class B(object):
+        reload_model = None; no_reload = False; save_path = str(tmp_path / 'm')
+    b = B()
+    utils.find_reload_model(b)
+    assert b.reload_model == p
+
+
+def test_python2_style_pickle_loads(tmp_path):
+    from asr_amd import utils
+    # a protocol-2 pickle holding latin1 bytes strings, as Python 2 writes numpy arrays
+    arr = np.arange(4, dtype=np.float32)
+    p = str(tmp_path / 'py2.pkl')
+    with open(p, 'wb') as f:
+        pickle.dump([[arr], None, 3], f, protocol=2)
+    vals, upd, epoch = utils.load_network_pickle(p)
+    assert epoch == 3 and np.array_equal(vals[0], arr)
+
+
+def test_gen_win_matches_reference_windowing():
+    from asr_amd import utils
+    B, T, D = 2, 23, 3
+    x = np.arange(B * T * D, dtype=np.float32).reshape(B, T, D)
+    m = np.ones((B, T), dtype=np.float32)
+    y = np.arange(B * T, dtype=np.int32).reshape(B, T)
+    wins = list(utils.gen_win((x, m, x, m, y, m), 10, right_context=4))
+    assert [w[0].shape[1] for w in wins] == [14, 13, 3]        # 0:14, 10:24 (clipped to 23), 20:23
+    assert np.array_equal(wins[1][0], x[:, 10:24]) and np.array_equal(wins[2][4], y[:, 20:23])
+    wins = list(utils.gen_win_test((x, m, None, None), 8))
+    assert [w[0].shape[1] for w in wins] == [8, 8, 7] and wins[0][2] is None
+
+
+def test_arg_parsers_and_save_path():
+    from asr_amd import arg_utils
+    a = arg_utils.get_arg_parser('deep_lstm').parse_args(
+        ['--num-units', '256', '--num-layers', '3', '--uni', '--num-tbptt-steps', '100', '--right-context', '5',
+         '--data-path', '/x/wsj_fbank123.h5', '--batch-size', '16'])
+    assert a.num_units == 256 and a.uni and not a.use_layer_norm and a.grad_clipping == 1.0
+    assert arg_utils.get_save_path(a) == 'wsj_fbank123_lr0.001_gc1.0_l3_n256_b16_uni_tb100_rc5_train_si284'
+    h = arg_utils.get_arg_parser('hyperlstm').parse_args(['--num-nodes', '512', '--num-hyper-nodes', '128',
+                                                         '--num-proj-nodes', '64', '--num-layers', '4'])
+    assert arg_utils.get_save_path(h, 'hyperlstm') == './wsj_hyperlstm_lr0.001_gc1.0_l4_n512_b2_hn128_pn64'
+    l = arg_utils.get_arg_parser('lhuclstm').parse_args([])
+    assert l.num_pred_units == 128 and l.num_pred_layers == 1 and l.layer_name == 'IVectorLHUCLSTMLayer'
+
+
+def test_utterance_stream_pads_like_fuel():
+    from asr_amd import data
+    utts = data.synthetic_set(5, D=4, C=7, I=3, min_len=2, max_len=9, seed=3)
+    ds = data.UtteranceStream(utts, 2)
+    batches = list(ds.get_epoch_iterator())
+    assert len(batches) == 3 == len(ds)
+    x, xm, iv, ivm, y, ym = batches[0]
+    lens = [u.features.shape[0] for u in utts[:2]]
+    assert x.shape == (2, max(lens), 4) and iv.shape == (2, max(lens), 3) and y.dtype == np.int32
+    assert np.array_equal(xm.sum(axis=1), lens) and np.array_equal(xm, ym)
+    for i, u in enumerate(utts[:2]):
+        assert np.array_equal(x[i, :lens[i]], u.features) and not x[i, lens[i]:].any()
+        assert np.array_equal(iv[i, 0], iv[i, lens[i] - 1])    # constant within the utterance
+    ids = list(data.UttIdStream(utts, 2).get_epoch_iterator())
+    assert ids[0] == (['utt0000', 'utt0001'],) and len(ids[2][0]) == 1
+    assert len(list(data.UtteranceStream(utts, 2, test=True).get_epoch_iterator())[0]) == 4
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter inventories (pickle order) -- pure python
+def test_param_inventories_match_survey_counts():
+    from asr_amd import specs
+    def count(sp):
+        return sum(int(np.prod(s)) for _, s, _ in sp)
+    # cfg3 per direction L1 2,185,728, L2-4 4,492,288; output 3,521,900; total 34.85 M
+    assert count(specs.hyper_params(123, 512, 128, 64)) == 2185728
+    assert count(specs.hyper_params(1024, 512, 128, 64)) == 4492288
+    assert count(specs.dense_params(1024, 3436)) == 3521900
+    names = [n for n, _, _ in specs.hyper_params(5, 8, 4, 2)]
+    assert names[:3] == ['W_hhat_ig', 'W_xhat_ig', 'bhat_ig'] and names[12:17] == [
+        'W_hhat_h_ig', 'b_hhat_h_ig', 'W_hhat_x_ig', 'b_hhat_x_ig', 'W_hhat_b_ig']
+    assert names[-2:] == ['W_h_og', 'W_x_og'] and len(names) == 12 + 20 + 16 + 8
+    names = [n for n, _, _ in specs.lstm_params(5, 8, 4, True)]
+    assert names[:3] == ['W_h_ig', 'W_x_ig', 'b_ig'] and names[12:] == [
+        'W_p', 'W_x_alpha', 'W_h_alpha', 'W_c_alpha', 'W_c_beta']
+    shapes = dict((n, s) for n, s, _ in specs.lstm_params(5, 8, 4, True))
+    assert shapes['W_h_ig'] == (4, 8) and shapes['W_p'] == (8, 4)
+    names = [n for n, _, _ in specs.icond_ln_prj_params(5, 8, 3, 6)]
+    assert names == ['W_in_to_ingate', 'W_hid_to_ingate', 'W_in_to_forgetgate', 'W_hid_to_forgetgate',
+                     'W_in_to_cell', 'W_hid_to_cell', 'W_in_to_outgate', 'W_hid_to_outgate', 'W_hid_prj',
+                     'W_cond_prj', 'b_cond_prj', 'W_alpha_in', 'b_alpha_in', 'W_alpha_hid', 'b_alpha_hid',
+                     'W_beta', 'b_beta']
+    names = [n for n, _, _ in specs.ln_prj_params(5, 8, 4)]
+    assert names[-7:] == ['W_alpha_in', 'W_beta_in', 'W_alpha_hid', 'W_beta_hid', 'W_alpha_cell',
+                          'W_beta_cell', 'W_hid_prj']
+
+
+# ------------------------------------------------------------------------------------------------
+# data parallel: sharding + bucketed all-reduce over gloo, world_size 2
+def test_shard_rows_partition():
+    from asr_amd import dp
+    lens = np.array([50, 10, 40, 20, 30, 60, 70, 5])
+    got = [dp.shard_rows(lens, r, 4) for r in range(4)]
+    assert sorted(np.concatenate(got).tolist()) == list(range(8))
+    assert [lens[g].tolist() for g in got] == [[5, 10], [20, 30], [40, 50], [60, 70]]
+    with pytest.raises(ValueError):
+        dp.shard_rows(lens, 0, 3)
+    x = np.zeros((8, 70, 2), dtype=np.float32)
+    m = (np.arange(70)[None, :] < lens[:, None]).astype(np.float32)
+    sx, sm = dp.shard_batch((x, m), 1, 4)
+    assert sx.shape == (2, 30, 2) and sm.sum() == 50
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from asr_amd import dp
+
+class Store(object):
+    pass
+
+class FakeNet(object):
+    """The slice of engine.Network that GradAllReduce touches, on the CPU."""
+    def __init__(self, n):
+        self.device = torch.device('cpu')
+        self.store = Store(); self.store.g = torch.zeros(n)
+        self.world = 1; self.grad_hook = None
+
+rank = int(os.environ['RANK']); world = int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+net = FakeNet(1000)
+ar = dp.GradAllReduce(net)
+assert net.world == 2 and net.grad_hook is not None
+rng = np.random.default_rng(7)
+full = [torch.from_numpy(rng.standard_normal(1000).astype(np.float32)) for _ in range(world)]
+net.store.g.copy_(full[rank])
+# buckets become final in reverse topological order (output layer first)
+for lo, hi in ((900, 1000), (500, 900), (0, 500)):
+    net.grad_hook(lo, hi)
+ar.finish()
+want = full[0] + full[1]
+assert torch.equal(net.store.g, want), (net.store.g - want).abs().max()
+s = ar.reduce_scalars(torch.tensor([1.0 + rank, 10.0]))
+assert s.tolist() == [3.0, 20.0]
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_gloo_world2_bucketed_allreduce(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_GLOO_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d ok' % r in o
