@@ -129,8 +129,15 @@ def main():
         byts = float(np.mean([rows * ndir * scan_bytes_per_row_dir(True) for rows, ndir, _ in bwd]))
         steps_per_launch = float(np.mean([rows / BATCH for rows, _, _ in bwd]))
         ach = byts / (ms * 1e-3) / 1e9
+        traffic = None       # HBM/fabric bytes per launch of the same kernel from the committed PMC passes
+        pj = os.path.join(ROOT, 'profiles', 'r01_pmc_hyper_scan_bwd.json')
+        if os.path.exists(pj):
+            with open(pj) as f:
+                pm = json.load(f)
+            traffic = (pm['fetch_size_kb_per_launch'] + pm['write_size_kb_per_launch']) * 1024.0
         roof = dict(bound='hbm', kernel='hyper_scan_bwd_kernel', achieved=ach, peak=8000.0, unit='GB/s',
-                    frac=ach / 8000.0, traffic=None, avg_launch_ms=ms,
+                    frac=ach / 8000.0, traffic=traffic, algorithmic_bytes_per_launch=byts,
+                    avg_launch_ms=ms,
                     us_per_timestep=ms * 1e3 / steps_per_launch,
                     fwd_kernel_avg_launch_ms=float(np.mean([t for _, _, t in fwd])),
                     scan_share_of_step=float(sum(t for _, _, t in bwd + fwd)) / (dt * 1e3))
