@@ -8,7 +8,9 @@ Internal conventions
     gradient buffer, so Adam, the gradient norm and the data-parallel all-reduce are single passes;
     `ref_views` give strided views with the reference's per-gate names/shapes for pickles.
 """
+import contextlib
 import ctypes as C
+import os
 import numpy as np
 import torch
 
@@ -529,6 +531,10 @@ class Network(object):
         self.world = 1               # data-parallel world size (loss normaliser = global batch)
         self.grad_hook = None        # called as grad_hook(lo, hi) when flat grads [lo,hi) are final
         self.scan_events = None      # list of (kind, backward, rows, ndir, ev0, ev1) when profiling
+        # parameter-gradient GEMMs of layer l run on a low-priority side stream under the BPTT scan
+        # of layer l-1 (the scan is latency-bound and leaves the MFMA pipes idle)
+        self.overlap = self.device.type == 'cuda' and os.environ.get('ASR_OVERLAP', '1') != '0'
+        self.side = None
 
     # ---- construction -------------------------------------------------------------------------
     def add_pair(self, pair, spec_per_dir):
@@ -623,6 +629,28 @@ class Network(object):
 
     def tbptt_layers(self):
         return [p for p in self.pairs if getattr(p, 'stateful', False)]
+
+    @contextlib.contextmanager
+    def deferred(self):
+        """Work issued inside runs after everything enqueued so far on the current stream, but off the
+        critical path (side stream); Network.backward() joins it before returning."""
+        if not self.overlap:
+            yield
+            return
+        if self.side is None:
+            try:
+                self.side = torch.cuda.Stream(device=self.device, priority=1)
+            except Exception:
+                self.side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            yield
+
+    def join_deferred(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     # ---- scan launch helpers ------------------------------------------------------------------
     def _workspace(self, key, nbytes):
@@ -746,16 +774,19 @@ class Network(object):
     def backward(self):
         """theano.grad(ce_cost, params) (libs/comp_graph_utils.py:73-75) into the flat grad buffer."""
         dl = self.dlogits
-        ops.gemm(self.top, dl, self.out.g('W'), ta=True)
-        ops.colreduce(dl, self.out.g('b'), dl.shape[0], self.C)
         dY = self.arena.mat('dtop', dl.shape[0], self.K_top)
         ops.gemm(dl, self.out.p('W'), dY, tb=True)
-        if self.grad_hook:
-            self.grad_hook(*self.param_range('out.'))
+        with self.deferred():
+            ops.gemm(self.top, dl, self.out.g('W'), ta=True)
+            ops.colreduce(dl, self.out.g('b'), dl.shape[0], self.C)
+            if self.grad_hook:
+                self.grad_hook(*self.param_range('out.'))
         for i in range(len(self.pairs) - 1, -1, -1):
             dY = self.pairs[i].backward(dY, need_dx=(i > 0))
             if self.grad_hook:
-                self.grad_hook(*self.param_range('L%d.' % i))
+                with self.deferred():          # after this layer's (deferred) parameter gradients
+                    self.grad_hook(*self.param_range('L%d.' % i))
+        self.join_deferred()
 
     def adam_update(self, lr, b1=0.9, b2=0.999, eps=1e-8, want_sqrt=True):
         """libs/lasagne_libs/updates.py:587-617 on the flat buffer + grads_norm

@@ -144,7 +144,22 @@ class HyperPair(object):
             c['dA'] = self._buf('dA%d' % d, rows, 4 * N); Dd.dA = c['dA'].data_ptr()
             c['dD'] = self._buf('dD%d' % d, rows, 12 * N); Dd.dD = c['dD'].data_ptr()
         net.scan_hyper(self, desc, backward=True)
+        # critical path first: dX feeds the BPTT scan of the layer below
         dX = self._buf('dX', rows, self.D) if need_dx else None
+        if need_dx:
+            for d, dp in enumerate(self.dirs):
+                c = ctx['d'][d]
+                ops.gemm(c['dXp'], dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+                ops.gemm(c['dXh'], dp.p('Wxh')[N:], dX, tb=True, beta=1.0)
+        # parameter gradients: nothing below depends on them, so they run on the side stream under
+        # the (latency-bound) scan of the layer below
+        with net.deferred():
+            self._param_grads(ctx, rows, T, B)
+        return dX
+
+    def _param_grads(self, ctx, rows, T, B):
+        N, H = self.N, self.H
+        X = ctx['X']
         n1 = (T - 1) * B
         for d, dp in enumerate(self.dirs):
             c = ctx['d'][d]
@@ -175,7 +190,3 @@ class HyperPair(object):
                 ops.gemm(dMg[:H, 2, g, :], dp.p('Wzb')[g], dp.g('Wz_b')[g], tb=True)
                 ops.gemm(dp.p('Wz_b')[g], dMg[:H, 2, g, :], dp.g('Wzb')[g], ta=True)
             dp.g('b0').copy_(dMg[H, 2])
-            if need_dx:
-                ops.gemm(dXp, dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
-                ops.gemm(dXh, dp.p('Wxh')[N:], dX, tb=True, beta=1.0)
-        return dX

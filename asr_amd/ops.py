@@ -29,10 +29,11 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
     M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
     K2, N = (B.shape[1], B.shape[0]) if tb else (B.shape[0], B.shape[1])
     assert K == K2 and tuple(Cm.shape) == (M, N), (A.shape, B.shape, Cm.shape, ta, tb)
-    ws = _gemm_ws.get(Cm.device)
+    key = (Cm.device, _s())                       # one split-K scratch per stream: launches on
+    ws = _gemm_ws.get(key)                        # different streams may overlap
     if ws is None:
         ws = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=Cm.device)     # split-K partials
-        _gemm_ws[Cm.device] = ws
+        _gemm_ws[key] = ws
     check(_lib.lib().asr_gemm_f32_ws(int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B),
                                      max(B.stride(0), 1), beta, _p(Cm), max(Cm.stride(0), 1), _p(bias),
                                      _p(ws), ws.numel() * 4, _s()), 'asr_gemm_f32_ws')
@@ -65,7 +66,7 @@ def colreduce(x, out, rows, n, y=None, gmod=1, accumulate=False, ldx=None, ldy=N
     """out[g,c] (+)= sum_{r % gmod == g} x[r,c] * (y[r,c] if y is given)."""
     L = _lib.lib()
     need = L.asr_colreduce_ws_bytes(n, gmod)
-    key = (x.device, )
+    key = (x.device, _s())
     ws = _cr_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(need // 4 + 16, dtype=torch.float32, device=x.device)
