@@ -454,28 +454,35 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     f32x4 n_g4 = {0, 0, 0, 0}, n_a4 = {0, 0, 0, 0}, n_dh4 = {0, 0, 0, 0}, n_dx4 = {0, 0, 0, 0}, n_x4 = {0, 0, 0, 0};
     f32x4 n_hg4 = {0, 0, 0, 0};
     float n_m = 0.f, n_cnew = 0.f, n_cprev = 0.f, n_dre = 0.f, n_hcnew = 0.f, n_hcprev = 0.f;
+    // Branch-free on purpose.  Any control-flow join behind these loads (`st > 0 ? load : 0`, a
+    // wave-role `if`, `if (step + 1 < T)`) makes hipcc place the phi copies of the loaded registers
+    // right behind the loads, i.e. an s_waitcnt vmcnt(0..1) that puts the whole memory latency
+    // (~3.4k cycles per step by the in-kernel stamps) on the critical path of every step.  So: every
+    // wave issues every load, every step; lanes / waves that do not own a tensor read a dummy line
+    // (address select, no branch), invalid batch rows read clamped in-range rows, and the selects
+    // on the VALUES happen one iteration later, where they are consumed.
+    const int bq = bvalid ? b : (B - 1);
+    const int huq = hvalid ? hu : 0;
+    const bool w0 = (wv == 0), w1 = (wv == 1);
+    const float* const dummy = D.wpack;
     auto prefetch = [&](int step) {
         const int st = T - 1 - step;
         const int t = D.reverse ? T - 1 - st : st;
-        const int tprev = D.reverse ? t + 1 : t - 1;
-        const size_t row = (size_t)t * B + b, rowp = (size_t)tprev * B + b;
-        if (!bvalid || wave >= 2) return;
-        n_m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
-        if (wave == 0) {
-            n_g4 = *(const f32x4*)(D.gates + row * 4 * N + col4);
-            const float* ad_ = D.aD + row * 12 * N;
-            n_a4 = *(const f32x4*)(ad_ + col4);
-            n_dh4 = *(const f32x4*)(ad_ + 4 * N + col4);
-            n_dx4 = *(const f32x4*)(ad_ + 8 * N + col4);
-            n_x4 = *(const f32x4*)(D.xproj + row * 4 * N + col4);
-            n_cnew = D.cst[row * N + unit];
-            n_cprev = st > 0 ? D.cst[rowp * N + unit] : 0.f;
-            n_dre = D.dr_ext[row * D.ld_dr + unit];
-        } else if (hvalid) {
-            n_hg4 = *(const f32x4*)(D.hgates + row * 4 * H + hu * 4);
-            n_hcnew = D.hcst[row * H + hu];
-            n_hcprev = st > 0 ? D.hcst[rowp * H + hu] : 0.f;
-        }
+        const int tprev = st > 0 ? (D.reverse ? t + 1 : t - 1) : t;
+        const size_t row = (size_t)t * B + bq, rowp = (size_t)tprev * B + bq;
+        const float* ad_ = D.aD + row * 12 * N;
+        n_m = *((w0 || w1) ? A.mask + ((size_t)bq * A.msb + (size_t)t * A.mst) : dummy);
+        n_g4 = *(const f32x4*)(w0 ? D.gates + row * 4 * N + col4 : dummy);
+        n_a4 = *(const f32x4*)(w0 ? ad_ + col4 : dummy);
+        n_dh4 = *(const f32x4*)(w0 ? ad_ + 4 * N + col4 : dummy);
+        n_dx4 = *(const f32x4*)(w0 ? ad_ + 8 * N + col4 : dummy);
+        n_x4 = *(const f32x4*)(w0 ? D.xproj + row * 4 * N + col4 : dummy);
+        n_cnew = *(w0 ? D.cst + row * N + unit : dummy);
+        n_cprev = *(w0 ? D.cst + rowp * N + unit : dummy);
+        n_dre = *(w0 ? D.dr_ext + row * D.ld_dr + unit : dummy);
+        n_hg4 = *(const f32x4*)(w1 ? D.hgates + row * 4 * H + huq * 4 : dummy);
+        n_hcnew = *(w1 ? D.hcst + row * H + huq : dummy);
+        n_hcprev = *(w1 ? D.hcst + rowp * H + huq : dummy);
     };
     prefetch(0);
     STAMP_DECL
@@ -484,11 +491,13 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         const int t = D.reverse ? T - 1 - st : st;
         const int par = step & 1;
         const size_t row = (size_t)t * B + b;
-        const float m = n_m;
+        const float m = bvalid ? n_m : 0.f;
         const bool on = (m != 0.f);
         const f32x4 g4 = n_g4, a4 = n_a4, dh4 = n_dh4, dx4 = n_dx4, x4 = n_x4, hg4 = n_hg4;
-        const float c_new = n_cnew, c_prev = n_cprev, dre = n_dre, hc_new = n_hcnew, hc_prev = n_hcprev;
-        if (step + 1 < T) prefetch(step + 1);
+        const float c_new = n_cnew, c_prev = st > 0 ? n_cprev : 0.f, dre = bvalid ? n_dre : 0.f;
+        const float hc_new = n_hcnew, hc_prev = st > 0 ? n_hcprev : 0.f;
+        prefetch(step + 1 < T ? step + 1 : step);
+        STAMP(9);
 
         // ---- S1: main cell backward (wave 0)
         f32x4 dg4 = {0, 0, 0, 0}, da4 = {0, 0, 0, 0}, dd_h = {0, 0, 0, 0}, dd_x = {0, 0, 0, 0};
@@ -516,6 +525,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             }
             da4 = dg4 * dh4;
             dd_h = dg4 * a4; dd_x = dg4 * x4;
+            STAMP(10);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dal[(q * 4 + k) * 16 + bl] = da4[k];
