@@ -381,10 +381,15 @@ class LstmPair(object):
         return Y
 
     def backward(self, dY, need_dx=True):
+        """BPTT of the pair.  Everything the layer below waits for (dR, the scan, the LN backward of
+        the input side, dX) is issued first on the current stream; the parameter gradients are
+        collected as closures and issued afterwards through net.deferred() (side stream, under the
+        scan of the layer below)."""
         net = self.net; ctx = self.ctx; N = self.N; P = self.P
         X, T, B, mask, cond = ctx['X'], ctx['T'], ctx['B'], ctx['mask'], ctx['cond']
         rows = T * B
         Pout = P if P else N
+        later = []
         desc = _lib.LstmScanDesc()
         desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
         desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
@@ -393,27 +398,15 @@ class LstmPair(object):
             c = ctx['d'][d]
             dYd = dY[:, d * Pout:(d + 1) * Pout]
             if self.kind == 'lhuc':
-                sf = c['sf']; hid = c['hid']; acts = c['acts']
-                dsf = self._buf('lh_dsf%d' % d, B, Pout)
-                ops.colreduce(dYd, dsf, rows, Pout, y=hid, gmod=B, ldx=dYd.stride(0), ldy=hid.stride(0))
-                ops.act_bwd(dsf, sf, B, Pout, 1)              # relu'(sf)
+                sf = c['sf']; hid = c['hid']
                 dhid = self._buf('lh_dhid%d' % d, rows, Pout)
                 ops.rowscale(dYd, dYd.stride(0), sf, B, True, dhid, Pout, rows, Pout)
-                ops.gemm(acts[-1], dsf, dp.g('We%d' % self.npl), ta=True)
-                ops.colreduce(dsf, dp.g('be%d' % self.npl), B, Pout)
-                da = dsf
-                for i in range(self.npl - 1, -1, -1):
-                    dprev = self._buf('lh_da%d_%d' % (i, d), B, self.npu)
-                    ops.gemm(da, dp.p('We%d' % (i + 1)), dprev, tb=True)
-                    ops.act_bwd(dprev, acts[i + 1], B, self.npu, 1)
-                    ops.gemm(acts[i], dprev, dp.g('We%d' % i), ta=True)
-                    ops.colreduce(dprev, dp.g('be%d' % i), B, self.npu)
-                    da = dprev
+                later.append(lambda d=d, dp=dp, c=c, dYd=dYd: self._lhuc_param_grads(d, dp, c, dYd, rows, B, Pout))
                 dYd = dhid
             if P:
                 dR = self._buf('dR%d' % d, rows, N)
                 ops.gemm(dYd, dp.p('Wp'), dR, tb=True)
-                ops.gemm(c['R'], dYd, dp.g('Wp'), ta=True)
+                later.append(lambda dp=dp, c=c, dYd=dYd: ops.gemm(c['R'], dYd, dp.g('Wp'), ta=True))
             else:
                 dR = dYd
             c['dR'] = dR
@@ -441,59 +434,84 @@ class LstmPair(object):
         dX = self._buf('dX', rows, self.D) if need_dx else None
         for d, dp in enumerate(self.dirs):
             c = ctx['d'][d]
-            dG = c['dG']; dA = c['dA'] if self.ln_kind else dG
-            R = c['R']
-            # dW' = sum_t r_{prev(t)}^T dA_t
-            dWf = self._buf('dWf%d' % d, N, 4 * N) if P else dp.g('Wh')
-            n1 = (T - 1) * B
-            if not self.reverse[d]:
-                Ra, dAb, first = R[:n1], dA[B:], dA[:B]
-            else:
-                Ra, dAb, first = R[B:], dA[:n1], dA[n1:]
-            ops.gemm(Ra, dAb, dWf, ta=True)
-            if 'r0' in c:
-                ops.gemm(c['r0'], first, dWf, ta=True, beta=1.0)
-            if P:
-                ops.gemm(dp.p('Wp'), dWf, dp.g('Wh'), ta=True)
-                ops.gemm(dWf, dp.p('Wh'), dp.g('Wp'), tb=True, beta=1.0)
-            if dp.has('b'):
-                ops.colreduce(dG, dp.g('b'), rows, 4 * N)
-            if self.cell_ln:
-                ops.colreduce(c['dOut'], dp.g('a_c'), rows, N, y=c['chat'])
-                ops.colreduce(c['dOut'], dp.g('b_c'), rows, N)
+            dG = c['dG']
             if self.ln_kind == 0:
                 dXp = dG
             else:
                 dXp = self._buf('dXp%d' % d, rows, 4 * N)
-                if self.ln_kind == 1:
-                    ops.colreduce(dG, dp.g('a_in'), rows, 4 * N, y=c['xhat_in'])
-                    ops.colreduce(dG, dp.g('a_hid'), rows, 4 * N, y=c['ahat'])
-                    if dp.has('b_in'):
-                        ops.colreduce(dG, dp.g('b_in'), rows, 4 * N)
-                        ops.colreduce(dG, dp.g('b_hid'), rows, 4 * N)
-                    ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], dp.p('a_in'), dXp)
-                else:
-                    F = self.F; Tc = cond.shape[1]
-                    dal_in = self._buf('dal_in%d' % d, B, 4 * N); dal_hid = self._buf('dal_hid%d' % d, B, 4 * N)
-                    dbt = self._buf('dbt%d' % d, B, 4 * N)
-                    ops.colreduce(dG, dal_in, rows, 4 * N, y=c['xhat_in'], gmod=B)
-                    ops.colreduce(dG, dal_hid, rows, 4 * N, y=c['ahat'], gmod=B)
-                    ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], c['al_in'], dXp, amod=B)
-                    ops.colreduce(dXp, dbt, rows, 4 * N, gmod=B)
-                    s = c['s']
-                    ds = self._buf('ds%d' % d, B, F)
-                    for k, (nm, dv) in enumerate((('ai', dal_in), ('ah', dal_hid), ('bt', dbt))):
-                        ops.gemm(s, dv, dp.g('W' + nm), ta=True)
-                        ops.colreduce(dv, dp.g('b' + nm), B, 4 * N)
-                        ops.gemm(dv, dp.p('W' + nm), ds, tb=True, beta=0.0 if k == 0 else 1.0)
-                    dpre = self._buf('dpre%d' % d, B * Tc, F)
-                    ops.masked_mean_tanh_bwd(ds, mask, c['pre'], B, Tc, F, dpre)
-                    ops.gemm(cond.view(B * Tc, self.I), dpre, dp.g('Wc'), ta=True)
-                    ops.colreduce(dpre, dp.g('bc'), B * Tc, F)
-            ops.gemm(X, dXp, dp.g('Wx'), ta=True)
+                al = dp.p('a_in') if self.ln_kind == 1 else c['al_in']
+                ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], al, dXp, amod=0 if self.ln_kind == 1 else B)
+            c['dXp'] = dXp
             if need_dx:
                 ops.gemm(dXp, dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+            later.append(lambda d=d, dp=dp, c=c: self._param_grads(d, dp, c, X, cond, mask, rows, T, B))
+        with net.deferred():
+            for fn in later:
+                fn()
         return dX
+
+    def _lhuc_param_grads(self, d, dp, c, dYd, rows, B, Pout):
+        sf = c['sf']; hid = c['hid']; acts = c['acts']
+        dsf = self._buf('lh_dsf%d' % d, B, Pout)
+        ops.colreduce(dYd, dsf, rows, Pout, y=hid, gmod=B, ldx=dYd.stride(0), ldy=hid.stride(0))
+        ops.act_bwd(dsf, sf, B, Pout, 1)              # relu'(sf)
+        ops.gemm(acts[-1], dsf, dp.g('We%d' % self.npl), ta=True)
+        ops.colreduce(dsf, dp.g('be%d' % self.npl), B, Pout)
+        da = dsf
+        for i in range(self.npl - 1, -1, -1):
+            dprev = self._buf('lh_da%d_%d' % (i, d), B, self.npu)
+            ops.gemm(da, dp.p('We%d' % (i + 1)), dprev, tb=True)
+            ops.act_bwd(dprev, acts[i + 1], B, self.npu, 1)
+            ops.gemm(acts[i], dprev, dp.g('We%d' % i), ta=True)
+            ops.colreduce(dprev, dp.g('be%d' % i), B, self.npu)
+            da = dprev
+
+    def _param_grads(self, d, dp, c, X, cond, mask, rows, T, B):
+        N = self.N; P = self.P
+        dG = c['dG']; dA = c['dA'] if self.ln_kind else dG
+        R = c['R']; dXp = c['dXp']
+        # dW' = sum_t r_{prev(t)}^T dA_t
+        dWf = self._buf('dWf%d' % d, N, 4 * N) if P else dp.g('Wh')
+        n1 = (T - 1) * B
+        if not self.reverse[d]:
+            Ra, dAb, first = R[:n1], dA[B:], dA[:B]
+        else:
+            Ra, dAb, first = R[B:], dA[:n1], dA[n1:]
+        ops.gemm(Ra, dAb, dWf, ta=True)
+        if 'r0' in c:
+            ops.gemm(c['r0'], first, dWf, ta=True, beta=1.0)
+        if P:
+            ops.gemm(dp.p('Wp'), dWf, dp.g('Wh'), ta=True)
+            ops.gemm(dWf, dp.p('Wh'), dp.g('Wp'), tb=True, beta=1.0)
+        if dp.has('b'):
+            ops.colreduce(dG, dp.g('b'), rows, 4 * N)
+        if self.cell_ln:
+            ops.colreduce(c['dOut'], dp.g('a_c'), rows, N, y=c['chat'])
+            ops.colreduce(c['dOut'], dp.g('b_c'), rows, N)
+        if self.ln_kind == 1:
+            ops.colreduce(dG, dp.g('a_in'), rows, 4 * N, y=c['xhat_in'])
+            ops.colreduce(dG, dp.g('a_hid'), rows, 4 * N, y=c['ahat'])
+            if dp.has('b_in'):
+                ops.colreduce(dG, dp.g('b_in'), rows, 4 * N)
+                ops.colreduce(dG, dp.g('b_hid'), rows, 4 * N)
+        elif self.ln_kind == 2:
+            F = self.F; Tc = cond.shape[1]
+            dal_in = self._buf('dal_in%d' % d, B, 4 * N); dal_hid = self._buf('dal_hid%d' % d, B, 4 * N)
+            dbt = self._buf('dbt%d' % d, B, 4 * N)
+            ops.colreduce(dG, dal_in, rows, 4 * N, y=c['xhat_in'], gmod=B)
+            ops.colreduce(dG, dal_hid, rows, 4 * N, y=c['ahat'], gmod=B)
+            ops.colreduce(dXp, dbt, rows, 4 * N, gmod=B)
+            s = c['s']
+            ds = self._buf('ds%d' % d, B, F)
+            for k, (nm, dv) in enumerate((('ai', dal_in), ('ah', dal_hid), ('bt', dbt))):
+                ops.gemm(s, dv, dp.g('W' + nm), ta=True)
+                ops.colreduce(dv, dp.g('b' + nm), B, 4 * N)
+                ops.gemm(dv, dp.p('W' + nm), ds, tb=True, beta=0.0 if k == 0 else 1.0)
+            dpre = self._buf('dpre%d' % d, B * Tc, F)
+            ops.masked_mean_tanh_bwd(ds, mask, c['pre'], B, Tc, F, dpre)
+            ops.gemm(cond.view(B * Tc, self.I), dpre, dp.g('Wc'), ta=True)
+            ops.colreduce(dpre, dp.g('bc'), B * Tc, F)
+        ops.gemm(X, dXp, dp.g('Wx'), ta=True)
 
 
 def _init_tensor(rng, shape, init):

@@ -58,6 +58,75 @@ def cpu_baseline(net, sample_len=160):
                        '(%d frames, %.1f s)' % (BATCH, sample_len, b['frames'], dt))
 
 
+def other_config(args, rank, world, dev):
+    """cfg2 / cfg4 / cfg5 training throughput (same timing protocol, no roofline block)."""
+    import torch.distributed as dist
+    from asr_amd import builders, dp, gating_hyper_nets as G, workloads
+    from asr_amd.utils import gen_win
+    cfg = args.cfg
+    tb = []
+    if cfg == 2:
+        net = G.deep_projection_ln_lstm_model(None, None, 123, 3436, 4, None, 512, 1.0, 0.0, device=dev, seed=1)
+        name = 'cfg2: 4x512 LN-LSTMP (P=256) bidirectional, C=3436, WSJ-shaped'
+    elif cfg == 4:
+        net, _ = G.deep_projection_ivector_ln_model(None, None, None, 123, 4174, 4, 4, 64, 512, 1.0, 0.0,
+                                                    cond_dim=100, device=dev, seed=1)
+        name = 'cfg4: 4x512 i-vector cond-LN LSTMP, C=4174, TED-shaped'
+    else:
+        net, _, tb = builders.build_deep_uni_lhuclstm_ivector_tbptt(
+            'IVectorLHUCLSTMLayer', None, None, 123, 4, 512, 0, 3436, 1, 128, 0, 0, 0, BATCH, 1.0, False, False,
+            100, True, device=dev, seed=1)
+        name = 'cfg5: 4x512 uni LHUC-LSTM, TBPTT window 100 (one Adam step per window), lengths U{2000..6000}'
+    ar = dp.GradAllReduce(net)
+    batches = []
+    for i in range(args.pool):
+        b = workloads.make_batch(cfg, BATCH, seed_offset=1000 * rank + i)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        batches.append(dict(x=t(b['x']), m=t(b['mask']), y=t(b['y']), iv=t(b['ivec']) if 'ivec' in b else None,
+                            frames=b['frames']))
+
+    def step(i):
+        b = batches[i % len(batches)]
+        if cfg != 5:
+            net.loss(b['x'], b['m'], b['y'], b['m'], b['iv']); net.backward(); ar.finish(); net.adam_update(1e-3)
+            return b['frames']
+        for l in tb:
+            l.reset(BATCH)
+        full = (b['x'], b['m'], b['iv'], b['m'], b['y'], b['m'])
+        for xw, mw, iw, _, yw, tmw in gen_win(full, 100, 0):
+            net.loss(xw, mw, yw, tmw, iw, True, 100); net.backward(); ar.finish(); net.adam_update(1e-3)
+        return b['frames']
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(); net.check_status()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time(); frames = 0
+    for i in range(args.steps):
+        frames += step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    net.check_status()
+    if world > 1:
+        tt = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
+        tmax = tt[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        fsum = tt[1:2].clone(); dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
+        dt = tmax.item(); frames = fsum.item()
+    if rank == 0:
+        print(json.dumps(dict(metric='train frames/sec (node)', value=frames / dt, unit='frames/s', n_gpus=world,
+                              steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
+                              higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+                              data='synthetic', config=dict(workload=name, per_gpu_batch=BATCH,
+                                                            parallelism='dp%d' % world))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -65,6 +134,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pool', type=int, default=4, help='distinct synthetic batches per rank')
+    ap.add_argument('--cfg', type=int, default=3, choices=[2, 3, 4, 5],
+                    help='3 = the headline workload (default); 2/4/5 = the other training configs of '
+                         'BASELINE.json, reported for DESIGN.md only')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
@@ -78,6 +150,8 @@ def main():
 
     from asr_amd.builders import build_deep_hyperlstm
     from asr_amd import workloads, dp
+    if args.cfg != 3:
+        return other_config(args, rank, world, dev)
 
     net = build_deep_hyperlstm('hyper', None, None, N_IN, N_LAYERS, N_UNITS, N_HYPER, N_Z, N_OUT, 1.0,
                                True, 0, device=dev, seed=1234)
