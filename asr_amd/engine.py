@@ -529,6 +529,8 @@ def _init_tensor(rng, shape, init):
     kind, v = init
     if kind == 'normal':
         return (rng.standard_normal(shape) * v).astype(np.float32)
+    if kind == 'uniform':                              # lasagne.init.Uniform(v): U(-v, v)
+        return rng.uniform(-v, v, shape).astype(np.float32)
     return np.full(shape, v, dtype=np.float32)
 
 

@@ -93,3 +93,105 @@ def dense_params(K, C):
     """Lasagne DenseLayer W (in,out), b (libs/builder_utils.py:44-45) and SequenceDenseLayer
     (libs/lasagne_libs/layers.py:77-82): GlorotUniform W, zero b."""
     return [('W', (K, C), 'glorot_uniform'), ('b', (C,), ('const', 0.0))]
+
+
+# ------------------------------------------------------------------------------------------------
+# The LSTM layer classes of libs/lasagne_libs/recurrent_layers.py as ONE parameterised family
+# (SURVEY.md Appendix A).  Variant keys:
+#   proj      None | 'factors' (num_factors or N/2, :322-324,:578-580) | 'half' (N/2, :856,:1120)
+#             | 'prjs' (num_prjs, :2155)
+#   ln        'none' | 'static' (ln / gate_ln) | 'sample' (sample_ln / sample_gate_ln)
+#   per_gate  normalise each gate's N columns separately (gate_ln :17-25, sample_gate_ln :34-42)
+#   ln_beta   static beta vectors on both LN terms (:711-712)
+#   bias      per-gate b parameters (forget gate initialised to 1.0, :100,:605)
+#   beta      for ln == 'sample': 'pre' = beta(B,4N) added to x.W BEFORE the LN (:968,:1233),
+#             'post' = added after both LN terms (:2824,:4937); with `bias` the static b joins it (:2807)
+#   cell_ln   outcell = ln(cell; alpha_cell, beta_cell) (:740,:2849)
+#   cond      None | 'own' (pooled from the layer's own input, :944-946) | 'ext' (external i-vector input)
+#   pool      'mean_tanh' (masked mean of tanh, :945-946) | 'max_relu' (unmasked max of relu, :1469-1470)
+#   cinit     init of W_alpha_in / W_alpha_hid / W_beta: 0 or Uniform(0.01) (:2735-2753)
+# ------------------------------------------------------------------------------------------------
+def _v(proj=None, ln='none', per_gate=False, ln_beta=False, bias=True, beta=None, cell_ln=False, cond=None,
+       pool='mean_tanh', cinit=0.0):
+    return dict(proj=proj, ln=ln, per_gate=per_gate, ln_beta=ln_beta, bias=bias, beta=beta, cell_ln=cell_ln,
+                cond=cond, pool=pool, cinit=cinit)
+
+
+REC_CLASSES = {
+    'LSTMLayer': _v(),                                                                   # :45
+    'ProjectLSTMLayer': _v(proj='factors'),                                              # :290
+    'LayerNormProjectLSTMLayer': _v(proj='factors', ln='static', ln_beta=True, cell_ln=True),   # :548
+    'CondLayerNormProjectLSTMLayer': _v(proj='half', ln='sample', bias=False, beta='pre', cond='own'),      # :816
+    'InputCondLayerNormProjectLSTMLayer': _v(proj='half', ln='sample', bias=False, beta='pre', cond='ext'),  # :1075
+    'MaxCondLayerNormProjectLSTMLayer': _v(proj='half', ln='sample', bias=False, beta='pre', cond='own',
+                                           pool='max_relu'),                              # :1340
+    'MaxInputCondLayerNormProjectLSTMLayer': _v(proj='half', ln='sample', bias=False, beta='pre', cond='ext',
+                                                pool='max_relu'),                         # :1599
+    'ProjectLSTM_v0_1_Layer': _v(proj='prjs'),                                            # :1868
+    'LayerNormProjectLSTM_v0_1_Layer': _v(proj='prjs', ln='static', cell_ln=True),        # :2125
+    'LayerNormProjectLSTM_v0_2_Layer': _v(proj='prjs', ln='static', per_gate=True, cell_ln=True),   # :2380
+    'CondLayerNormProjectLSTM_v0_1_Layer': _v(proj='prjs', ln='sample', beta='post', cell_ln=True, cond='own',
+                                              cinit=0.01),                                # :2635
+    'CondLayerNormProjectLSTM_v0_2_Layer': _v(proj='prjs', ln='sample', per_gate=True, beta='post', cell_ln=True,
+                                              cond='own', cinit=0.01),                    # :2926
+    'RegularLSTM_v0_1_Layer': _v(),                                                       # :3220
+    'LayerNormRegularLSTM_v0_1_Layer': _v(ln='static', cell_ln=True),                     # :3467
+    'LayerNormRegularLSTM_v0_2_Layer': _v(ln='static', per_gate=True, cell_ln=True),      # :3712
+    'CondLayerNormRegularLSTM_v0_1_Layer': _v(ln='sample', beta='post', cell_ln=True, cond='own', cinit=0.01),   # :3957
+    'CondLayerNormRegularLSTM_v0_2_Layer': _v(ln='sample', per_gate=True, beta='post', cell_ln=True, cond='own',
+                                              cinit=0.01),                                # :4238
+    'LayerNormLSTMLayer': _v(ln='static', ln_beta=True, cell_ln=True),                    # :4522
+    'CondLayerNormLSTMLayer': _v(ln='sample', bias=False, beta='post', cond='own'),       # :4778
+    'InputCondLayerNormLSTMLayer': _v(ln='sample', bias=False, beta='post', cond='ext'),  # :5034
+}
+
+
+def rec_out_width(cls, N, num_factors=None, num_prjs=None):
+    """Width of the recurrent / output hidden vector (0 = no projection, i.e. N)."""
+    proj = REC_CLASSES[cls]['proj']
+    if proj is None:
+        return 0
+    if proj == 'factors':
+        return num_factors or N // 2
+    if proj == 'half':
+        return N // 2
+    return num_prjs
+
+
+def rec_params(cls, D, N, num_factors=None, num_prjs=None, cond_dim=0):
+    """(name, shape, init) in add_param order for a class of REC_CLASSES (peepholes=False and
+    learn_init=False, the defaults every builder of models/gating_hyper_nets.py uses)."""
+    v = REC_CLASSES[cls]
+    P = rec_out_width(cls, N, num_factors, num_prjs)
+    K = P if P else N
+    F = num_factors
+    out = []
+    for g in GATES_REC:
+        out += [('W_in_to_' + g, (D, N), 'orthogonal'), ('W_hid_to_' + g, (K, N), 'orthogonal')]
+        if v['bias']:
+            out.append(('b_' + g, (N,), ('const', 1.0 if g == 'forgetgate' else 0.0)))
+    if P and v['cond']:
+        out.append(('W_hid_prj', (N, P), 'orthogonal'))
+    if v['ln'] == 'static':
+        out.append(('W_alpha_in', (4 * N,), ('const', 1.0)))
+        if v['ln_beta']:
+            out.append(('W_beta_in', (4 * N,), ('const', 0.0)))
+        out.append(('W_alpha_hid', (4 * N,), ('const', 1.0)))
+        if v['ln_beta']:
+            out.append(('W_beta_hid', (4 * N,), ('const', 0.0)))
+        if v['cell_ln']:
+            out += [('W_alpha_cell', (N,), ('const', 1.0)), ('W_beta_cell', (N,), ('const', 0.0))]
+    if v['cond']:
+        cin = D if v['cond'] == 'own' else cond_dim
+        wi = ('uniform', v['cinit']) if v['cinit'] else ('const', 0.0)
+        out += [('W_cond_prj', (cin, F), 'orthogonal'), ('b_cond_prj', (F,), ('const', 0.0)),
+                ('W_alpha_in', (F, 4 * N), wi), ('b_alpha_in', (4 * N,), ('const', 1.0)),
+                ('W_alpha_hid', (F, 4 * N), wi), ('b_alpha_hid', (4 * N,), ('const', 1.0)),
+                ('W_beta', (F, 4 * N), wi)]
+        if not v['bias']:
+            out.append(('b_beta', (4 * N,), ('const', 0.0)))
+        if v['cell_ln']:      # the reference names the cell beta "num_factors" (:2762-2766, a typo kept
+            out += [('W_alpha_cell', (N,), ('const', 1.0)), ('num_factors', (N,), ('const', 0.0))]   # for pickles)
+    if P and not v['cond']:
+        out.append(('W_hid_prj', (N, P), 'orthogonal'))
+    return out

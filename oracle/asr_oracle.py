@@ -35,23 +35,29 @@ def _clip(g, c):
 # --------------------------------------------------------------------------------------------
 # layer norm  (libs/lhuclstm_layers.py:16-21, libs/lasagne_libs/recurrent_layers.py:10-15,27-32)
 # --------------------------------------------------------------------------------------------
-def ln_fwd(x, alpha, beta=None):
-    """y = alpha * (x - mean) / sqrt(var + eps) [+ beta]; alpha/beta are (n,) or per-sample (B,n)."""
-    mu = x.mean(axis=1, keepdims=True)
-    var = x.var(axis=1, keepdims=True)
+def ln_fwd(x, alpha, beta=None, groups=1):
+    """y = alpha * (x - mean) / sqrt(var + eps) [+ beta]; alpha/beta are (n,) or per-sample (B,n).
+    groups=4: gate_ln / sample_gate_ln (recurrent_layers.py:17-25,34-42): each of the 4 contiguous
+    gate blocks of a row is normalised separately."""
+    B, n = x.shape
+    xg = x.reshape(B, groups, n // groups)
+    mu = xg.mean(axis=2, keepdims=True)
+    var = xg.var(axis=2, keepdims=True)
     s = np.sqrt(var + EPS)
-    xh = (x - mu) / s
+    xh = ((xg - mu) / s).reshape(B, n)
     y = alpha * xh
     if beta is not None:
         y = y + beta
-    return y, (xh, s)
+    return y, (xh, s, groups)
 
 
 def ln_bwd(dy, alpha, cache):
-    xh, s = cache
-    dxh = dy * alpha
-    dx = (dxh - dxh.mean(axis=1, keepdims=True) - xh * (dxh * xh).mean(axis=1, keepdims=True)) / s
-    return dx, dy * xh, dy        # dx, per-sample dalpha, per-sample dbeta
+    xh, s, groups = cache
+    B, n = dy.shape
+    dxh = (dy * alpha).reshape(B, groups, n // groups)
+    xg = xh.reshape(B, groups, n // groups)
+    dx = (dxh - dxh.mean(axis=2, keepdims=True) - xg * (dxh * xg).mean(axis=2, keepdims=True)) / s
+    return dx.reshape(B, n), dy * xh, dy        # dx, per-sample dalpha, per-sample dbeta
 
 
 # --------------------------------------------------------------------------------------------
@@ -84,8 +90,9 @@ def lstm_scan_fwd(xin, mask, p, spec, c0=None, h0=None):
         a = h @ p['W_h']
         ci = ch = cc = None
         if ln != 'none':
-            gi, ci = ln_fwd(xin[t], p['alpha_in'], p.get('beta_in'))
-            gh, ch = ln_fwd(a, p['alpha_hid'], p.get('beta_hid'))
+            grp = 4 if spec.get('per_gate') else 1
+            gi, ci = ln_fwd(xin[t], p['alpha_in'], p.get('beta_in'), grp)
+            gh, ch = ln_fwd(a, p['alpha_hid'], p.get('beta_hid'), grp)
             gates = gi + gh
         else:
             gates = xin[t] + a
@@ -150,8 +157,8 @@ def lstm_scan_bwd(dhid, cache, p, spec, dcell=None):
                                  dc_new * i * (1 - g * g), do * o * (1 - o)], axis=1)
         dgates = _clip(dgates, clipv)
         dc_prev = dc_prev + dc_new * f
-        if p.get('b') is not None:
-            g_['b'] += dgates.sum(0)
+        if p.get('b') is not None:       # (4N,) static bias, or (B,4N) per-sample beta added after LN
+            g_['b'] += dgates if p['b'].ndim == 2 else dgates.sum(0)
         if ln != 'none':
             dx_t, dal, dbe = ln_bwd(dgates, p['alpha_in'], ci)
             g_['alpha_in'] += dal if ln == 'sample' else dal.sum(0)
@@ -508,6 +515,110 @@ class InputCondLayerNormProjectLSTMLayerO(OracleLayer):
         return _tm(dxin @ self.Wx.T)
 
 
+class RecLayerO(OracleLayer):
+    """Every LSTM layer class of libs/lasagne_libs/recurrent_layers.py as one parameterised
+    restatement (variant table: SURVEY.md Appendix A; the table itself is passed in by the caller as
+    `variant`, keys documented in asr_amd/specs.py REC_CLASSES, so that the oracle imports nothing
+    from the product).  Line references per variant key:
+      cond prologue, masked mean of tanh  :944-946 (own input), :1209-1211 (external)
+      cond prologue, unmasked max of relu :1468-1470, :1733-1735
+      alpha_in / alpha_hid / beta (B,4N)  :950-952, :1215-1217;  beta = s.W_beta + b_stacked :2807
+      beta before LN (added to x.W)       :968, :1233;   beta after LN :2824, :4937
+      static LN + b_stacked               :711-713, :2276-2278;  per-gate LN :2531-2532, :3113-3114
+      cell LN                             :740, :2305, :2849;    projection :748"""
+    def __init__(self, P, variant, num_units, out_width=0, grad_clipping=0, backwards=False, cls=None):
+        self.P = P; self.v = variant; self.N = num_units; self.Pw = out_width
+        v = variant
+        self.spec = dict(N=num_units, P=out_width, ln=v['ln'], per_gate=v['per_gate'], cell_ln=v['cell_ln'],
+                         grad_clip=grad_clipping, backwards=backwards)
+
+    def forward(self, x, mask, cond=None):
+        P = self.P; v = self.v
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        self.Wx = _stack(P, 'W_in_to_{}', GATES_REC)
+        xin = self.x @ self.Wx
+        p = dict(W_h=_stack(P, 'W_hid_to_{}', GATES_REC), W_p=P.get('W_hid_prj'), b=None)
+        b_st = _stack(P, 'b_{}', GATES_REC, axis=0) if v['bias'] else None
+        if v['cond']:
+            src = x if v['cond'] == 'own' else cond
+            a = src @ P['W_cond_prj'] + P['b_cond_prj']
+            if v['pool'] == 'mean_tanh':
+                pre = np.tanh(a)
+                msum = mask.sum(axis=1, keepdims=True)
+                sfeat = (pre * mask[:, :, None]).sum(axis=1) / msum
+                self.msum = msum
+            else:
+                pre = np.maximum(a, 0)
+                sfeat = pre.max(axis=1)
+            self.src = src; self.a = a; self.pre = pre; self.maskbt = mask; self.s = sfeat
+            p['alpha_in'] = sfeat @ P['W_alpha_in'] + P['b_alpha_in']
+            p['alpha_hid'] = sfeat @ P['W_alpha_hid'] + P['b_alpha_hid']
+            beta = sfeat @ P['W_beta'] + (b_st if v['bias'] else P['b_beta'])
+            if v['beta'] == 'pre':
+                xin = xin + beta[None]
+            else:
+                p['b'] = beta
+        else:
+            p['b'] = b_st
+            if v['ln'] == 'static':
+                p['alpha_in'] = P['W_alpha_in']; p['alpha_hid'] = P['W_alpha_hid']
+                if v['ln_beta']:
+                    p['beta_in'] = P['W_beta_in']; p['beta_hid'] = P['W_beta_hid']
+        if v['cell_ln']:
+            p['alpha_c'] = P['W_alpha_cell']
+            p['beta_c'] = P['num_factors'] if v['cond'] else P['W_beta_cell']
+        self.p = p
+        hid, _, self.cache = lstm_scan_fwd(xin, m, p, self.spec)
+        return _tm(hid)
+
+    def get_sample_feat(self):
+        return self.s
+
+    def backward(self, dy):
+        P = self.P; v = self.v
+        dxin, g, _ = lstm_scan_bwd(_tm(dy), self.cache, self.p, self.spec)
+        T, B, D = self.x.shape
+        G = {}
+        _unstack_into(G, 'W_hid_to_{}', GATES_REC, g['W_h'])
+        _unstack_into(G, 'W_in_to_{}', GATES_REC, self.x.reshape(T * B, D).T @ dxin.reshape(T * B, -1))
+        if self.Pw:
+            G['W_hid_prj'] = g['W_p']
+        dx = _tm(dxin @ self.Wx.T)
+        if v['cell_ln']:
+            G['W_alpha_cell'] = g['alpha_c']
+            G['num_factors' if v['cond'] else 'W_beta_cell'] = g['beta_c']
+        if v['cond']:
+            dbeta = dxin.sum(0) if v['beta'] == 'pre' else g['b']
+            dal_in, dal_hid = g['alpha_in'], g['alpha_hid']
+            sf = self.s
+            G['W_alpha_in'] = sf.T @ dal_in; G['b_alpha_in'] = dal_in.sum(0)
+            G['W_alpha_hid'] = sf.T @ dal_hid; G['b_alpha_hid'] = dal_hid.sum(0)
+            G['W_beta'] = sf.T @ dbeta
+            if v['bias']:
+                _unstack_into(G, 'b_{}', GATES_REC, dbeta.sum(0), axis=0)
+            else:
+                G['b_beta'] = dbeta.sum(0)
+            ds = dal_in @ P['W_alpha_in'].T + dal_hid @ P['W_alpha_hid'].T + dbeta @ P['W_beta'].T
+            if v['pool'] == 'mean_tanh':
+                da = (ds / self.msum)[:, None, :] * self.maskbt[:, :, None] * (1 - self.pre ** 2)
+            else:      # T.max gradient goes to every position equal to the max, then relu'
+                da = ds[:, None, :] * (self.pre == self.s[:, None, :]) * (self.a > 0)
+            Bc, Tc, I = self.src.shape
+            G['W_cond_prj'] = self.src.reshape(Bc * Tc, I).T @ da.reshape(Bc * Tc, -1)
+            G['b_cond_prj'] = da.sum((0, 1))
+            if v['cond'] == 'own':
+                dx = dx + da @ P['W_cond_prj'].T
+        else:
+            if v['bias']:
+                _unstack_into(G, 'b_{}', GATES_REC, g['b'], axis=0)
+            if v['ln'] == 'static':
+                G['W_alpha_in'] = g['alpha_in']; G['W_alpha_hid'] = g['alpha_hid']
+                if v['ln_beta']:
+                    G['W_beta_in'] = g['beta_in']; G['W_beta_hid'] = g['beta_hid']
+        self.grads = G
+        return dx
+
+
 class HyperLSTMLayerO(OracleLayer):
     """libs/lasagne_libs/hyper_lhuc_layers.py:168-507."""
     def __init__(self, P, num_units, num_hyper_units, num_proj_units, grad_clipping=0, backwards=False):
@@ -597,7 +708,7 @@ def gen_win(batch, win_size, right_context=0):
 # --------------------------------------------------------------------------------------------
 _KINDS = dict(lstm=LSTMLayerO, lhuc=LHUCLSTMLayerO, prj=ProjectLSTMLayerO,
               ln_prj=LayerNormProjectLSTMLayerO, icond_ln_prj=InputCondLayerNormProjectLSTMLayerO,
-              hyper=HyperLSTMLayerO)
+              hyper=HyperLSTMLayerO, rec=RecLayerO)
 
 
 class OracleNetwork(object):

@@ -18,6 +18,8 @@ def init_value(rng, shape, init, perturb=0.05):
     kind, v = init
     if kind == 'normal':
         return rng.standard_normal(shape) * v
+    if kind == 'uniform':
+        return rng.uniform(-v, v, shape) + rng.standard_normal(shape) * perturb
     return np.full(shape, v, dtype=np.float64) + rng.standard_normal(shape) * perturb
 
 

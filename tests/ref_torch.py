@@ -183,3 +183,119 @@ def hyper_layer(P, x, mask, N, H, Z, clip=0, backwards=False):
     outs = _scan(step, [orig, inp, m], [z(H), z(H), z(N), z(N)], backwards)
     hid_out = outs[3].transpose(0, 1)
     return hid_out.flip(1) if backwards else hid_out
+
+
+# ------------------------------------------------------------------------------------------------
+# The 20 LSTM layer classes of libs/lasagne_libs/recurrent_layers.py, written class by class after
+# their get_output_for bodies (NOT from the oracle's variant table, so that it pins that table).
+def gate_ln(x, alpha, beta=None):                  # :17-25 (static) and :34-42 (per sample)
+    B = x.shape[0]
+    ga = alpha.reshape(1 if alpha.dim() == 1 else B, 4, -1)
+    gi = x.reshape(B, 4, -1)
+    go = (gi - gi.mean(2, keepdim=True)) / torch.sqrt(gi.var(2, keepdim=True, unbiased=False) + EPS)
+    go = ga * go
+    if beta is not None:
+        go = go + beta.reshape(1 if beta.dim() == 1 else B, 4, -1)
+    return go.reshape(B, -1)
+
+
+def _pool_mean_tanh(src, mask, P):                 # :944-946 / :1209-1211
+    li = torch.tanh(src @ P['W_cond_prj'] + P['b_cond_prj'])
+    return (li * mask.unsqueeze(-1)).sum(1) / mask.sum(1, keepdim=True)
+
+
+class _TheanoMax(torch.autograd.Function):
+    """T.max(x, axis=1) with Theano's gradient (MaxAndArgmax.grad: g * eq(max, x), i.e. EVERY tied
+    position receives the gradient; torch.max would pick one).  Ties are the normal case for the
+    external i-vector input, which is constant over the frames of an utterance."""
+    @staticmethod
+    def forward(ctx, x):
+        mx = x.max(dim=1).values
+        ctx.save_for_backward((x == mx.unsqueeze(1)).to(x.dtype))
+        return mx
+
+    @staticmethod
+    def backward(ctx, g):
+        (eq,) = ctx.saved_tensors
+        return g.unsqueeze(1) * eq
+
+
+def _pool_max_relu(src, mask, P):                  # :1468-1470 / :1733-1735 (mask unused there)
+    li = torch.relu(src @ P['W_cond_prj'] + P['b_cond_prj'])
+    return _TheanoMax.apply(li)
+
+
+def rec_layer(P, cls, x, mask, N, clip=0, backwards=False, cond=None):
+    W_in = _cat(P, 'W_in_to_{}', G_R); W_hid = _cat(P, 'W_hid_to_{}', G_R)
+    K = W_hid.shape[0]
+    inp = x.transpose(0, 1)
+    m = mask.transpose(0, 1).unsqueeze(-1)
+    B = inp.shape[1]
+    has_b = ('b_ingate' in P)
+    b_stacked = _cat(P, 'b_{}', G_R, 0) if has_b else None
+    alpha_in = alpha_hid = beta = None
+    # ---- prologue
+    if cls in ('LSTMLayer', 'ProjectLSTMLayer', 'ProjectLSTM_v0_1_Layer', 'RegularLSTM_v0_1_Layer'):
+        inp = inp @ W_in + b_stacked                                   # :174, :431, :2007, :3351
+    elif cls in ('CondLayerNormProjectLSTMLayer', 'InputCondLayerNormProjectLSTMLayer',
+                 'MaxCondLayerNormProjectLSTMLayer', 'MaxInputCondLayerNormProjectLSTMLayer'):
+        src = x if cls in ('CondLayerNormProjectLSTMLayer', 'MaxCondLayerNormProjectLSTMLayer') else cond
+        li = (_pool_max_relu if cls.startswith('Max') else _pool_mean_tanh)(src, mask, P)
+        alpha_in = li @ P['W_alpha_in'] + P['b_alpha_in']
+        alpha_hid = li @ P['W_alpha_hid'] + P['b_alpha_hid']
+        beta = li @ P['W_beta'] + P['b_beta']
+        inp = inp @ W_in + beta                                        # :968, :1233, :1492, :1757
+    elif cls in ('CondLayerNormProjectLSTM_v0_1_Layer', 'CondLayerNormProjectLSTM_v0_2_Layer',
+                 'CondLayerNormRegularLSTM_v0_1_Layer', 'CondLayerNormRegularLSTM_v0_2_Layer'):
+        li = _pool_mean_tanh(x, mask, P)                               # :2799-2801
+        alpha_in = li @ P['W_alpha_in'] + P['b_alpha_in']
+        alpha_hid = li @ P['W_alpha_hid'] + P['b_alpha_hid']
+        beta = li @ P['W_beta'] + b_stacked                            # :2807
+        inp = inp @ W_in
+    elif cls in ('CondLayerNormLSTMLayer', 'InputCondLayerNormLSTMLayer'):
+        li = _pool_mean_tanh(x if cls == 'CondLayerNormLSTMLayer' else cond, mask, P)   # :4902-4904, :5163-5165
+        alpha_in = li @ P['W_alpha_in'] + P['b_alpha_in']
+        alpha_hid = li @ P['W_alpha_hid'] + P['b_alpha_hid']
+        beta = li @ P['W_beta'] + P['b_beta']
+        inp = inp @ W_in                                               # :4926
+    else:
+        inp = inp @ W_in                                               # static LN classes: :701, :2266
+
+    def step(input_n, mask_n, cell_previous, hid_previous):
+        hw = hid_previous @ W_hid
+        if cls in ('LSTMLayer', 'ProjectLSTMLayer', 'ProjectLSTM_v0_1_Layer', 'RegularLSTM_v0_1_Layer'):
+            gates = input_n + hw
+        elif cls in ('LayerNormProjectLSTMLayer', 'LayerNormLSTMLayer'):
+            gates = ln(input_n, P['W_alpha_in'], P['W_beta_in']) + ln(hw, P['W_alpha_hid'], P['W_beta_hid'])
+            gates = gates + b_stacked                                  # :711-713, :4675-4677
+        elif cls in ('LayerNormProjectLSTM_v0_1_Layer', 'LayerNormRegularLSTM_v0_1_Layer'):
+            gates = ln(input_n, P['W_alpha_in']) + ln(hw, P['W_alpha_hid']) + b_stacked   # :2276-2278
+        elif cls in ('LayerNormProjectLSTM_v0_2_Layer', 'LayerNormRegularLSTM_v0_2_Layer'):
+            gates = gate_ln(input_n, P['W_alpha_in']) + gate_ln(hw, P['W_alpha_hid']) + b_stacked   # :2531-2533
+        elif cls in ('CondLayerNormProjectLSTM_v0_1_Layer', 'CondLayerNormRegularLSTM_v0_1_Layer',
+                     'CondLayerNormLSTMLayer', 'InputCondLayerNormLSTMLayer'):
+            gates = ln(input_n, alpha_in) + ln(hw, alpha_hid) + beta   # :2822-2824, :4935-4937
+        elif cls in ('CondLayerNormProjectLSTM_v0_2_Layer', 'CondLayerNormRegularLSTM_v0_2_Layer'):
+            gates = gate_ln(input_n, alpha_in) + gate_ln(hw, alpha_hid) + beta          # :3113-3115
+        else:                                                          # sample_ln, beta already in input_n
+            gates = ln(input_n, alpha_in) + ln(hw, alpha_hid)          # :976-977, :1241-1242
+        ig, fg, ci, og = [grad_clip(gates[:, k * N:(k + 1) * N], clip) for k in range(4)]
+        ig = torch.sigmoid(ig); fg = torch.sigmoid(fg); ci = torch.tanh(ci)
+        cell = fg * cell_previous + ig * ci
+        if 'W_alpha_cell' in P:                                        # :740, :2305, :2849
+            outcell = ln(cell, P['W_alpha_cell'], P['num_factors'] if 'num_factors' in P else P['W_beta_cell'])
+        else:
+            outcell = cell
+        outcell = grad_clip(outcell, clip)
+        og = torch.sigmoid(og)
+        hid = og * torch.tanh(outcell)
+        if 'W_hid_prj' in P:
+            hid = hid @ P['W_hid_prj']
+        cell = torch.where(mask_n != 0, cell, cell_previous)
+        hid = torch.where(mask_n != 0, hid, hid_previous)
+        return [cell, hid]
+
+    init = [torch.zeros(B, N, dtype=x.dtype), torch.zeros(B, K, dtype=x.dtype)]
+    _, hid_out = _scan(step, [inp, m], init, backwards)
+    hid_out = hid_out.transpose(0, 1)
+    return hid_out.flip(1) if backwards else hid_out

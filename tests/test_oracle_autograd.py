@@ -82,6 +82,22 @@ def test_prj_family(backwards, clip, kind):
 
 @pytest.mark.parametrize('backwards', [False, True])
 @pytest.mark.parametrize('clip', [0, 0.3])
+@pytest.mark.parametrize('cls', sorted(specs.REC_CLASSES))
+def test_recurrent_layers_family(cls, backwards, clip):
+    """All 20 classes of libs/lasagne_libs/recurrent_layers.py: the oracle's variant-table layer
+    against the class-by-class torch transliteration."""
+    rng = np.random.default_rng(17)
+    v = specs.REC_CLASSES[cls]
+    P = make_params(rng, specs.rec_params(cls, D, N, F if v['cond'] else PJ, PJ, I), perturb=0.2, scale=1.5)
+    Pw = specs.rec_out_width(cls, N, F if v['cond'] else PJ, PJ)
+    b = make_batch(rng, B, T, D, C, I=I)
+    lay = O.RecLayerO(P, v, N, Pw, clip, backwards)
+    cond = b['ivec'] if v['cond'] == 'ext' else None
+    _check(lay, lambda Pt, x, m, c: R.rec_layer(Pt, cls, x, m, N, clip, backwards, c), P, b['x'], b['mask'], cond)
+
+
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip', [0, 0.3])
 def test_hyper_layer(backwards, clip):
     rng = np.random.default_rng(14)
     P = make_params(rng, specs.hyper_params(D, N, H, Z), perturb=0.3, scale=1.5)
