@@ -52,6 +52,8 @@ _SIGS = {
     'asr_rowscale': (i32, [fp, i32, fp, i32, i32, fp, i32, i32, i32, fp]),
     'asr_masked_mean': (i32, [fp, fp, i32, i32, i32, fp, fp]),
     'asr_masked_mean_tanh_bwd': (i32, [fp, fp, fp, i32, i32, i32, fp, fp]),
+    'asr_seq_pool_fwd': (i32, [fp, sz, sz, fp, i32, i32, i32, i32, fp, fp]),
+    'asr_seq_pool_bwd': (i32, [fp, fp, fp, sz, sz, fp, i32, i32, i32, i32, fp, fp]),
     'asr_softmax_ce': (i32, [fp, i32, i32, i32, fp, i32, i32, fp, i32, i32, f32, fp, fp, fp, fp, i32,
                              fp, fp]),
     'asr_reduce_sum': (i32, [fp, sz, fp, i32, fp]),

@@ -284,6 +284,83 @@ extern "C" int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, cons
     return ASR_OK;
 }
 
+// ------------------------------------------------------------------ strided sequence pooling
+// The conditioning prologue of the cond-LN layers pools an activation over time per utterance:
+//   mode 0: masked mean of tanh(.)  (recurrent_layers.py:945-946, :1210-1211)
+//   mode 1: unmasked max of relu(.) (:1469-1470, :1734-1735)
+// x holds the ACTIVATED values, element (b,t,f) at x[b*sb + t*st + f] (time-major own-input pooling:
+// sb = F, st = B*F; batch-major i-vector pooling: sb = T*F, st = F); mask is (B,T) contiguous.
+__global__ void seq_pool_fwd_kernel(const float* __restrict__ x, size_t sb, size_t st,
+                                    const float* __restrict__ mask, int T, int F, int mode,
+                                    float* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int f = blockIdx.y * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float* xb = x + (size_t)b * sb + f;
+    if (mode == 0) {
+        float acc = 0.f, msum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float m = mask[(size_t)b * T + t];
+            acc += xb[(size_t)t * st] * m;
+            msum += m;
+        }
+        out[(size_t)b * F + f] = acc / msum;
+    } else {
+        float mx = xb[0];
+        for (int t = 1; t < T; ++t) mx = fmaxf(mx, xb[(size_t)t * st]);
+        out[(size_t)b * F + f] = mx;
+    }
+}
+extern "C" int asr_seq_pool_fwd(const float* x, size_t sb, size_t st, const float* mask, int B, int T, int F,
+                                int mode, float* out, hipStream_t stream) {
+    if (B < 0 || T <= 0 || F <= 0 || !x || !out || (mode == 0 && !mask) || mode < 0 || mode > 1) return ASR_ERR_ARG;
+    if (!B) return ASR_OK;
+    hipLaunchKernelGGL(seq_pool_fwd_kernel, dim3(B, (F + 63) / 64), dim3(64), 0, stream, x, sb, st, mask, T, F,
+                       mode, out);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+// backward incl. the activation derivative; dx has the layout of x.
+//   mode 0: dx = ds[b,f] / sum_t mask * mask[b,t] * (1 - x^2)
+//   mode 1: dx = ds[b,f] * (x == s[b,f]) * (x > 0)   (Theano's max gradient reaches every tied frame)
+__global__ void seq_pool_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                    const float* __restrict__ x, size_t sb, size_t st,
+                                    const float* __restrict__ mask, int T, int F, int mode,
+                                    float* __restrict__ dx) {
+    const int b = blockIdx.x;
+    const int f = blockIdx.y * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const size_t base = (size_t)b * sb + f;
+    const float d = ds[(size_t)b * F + f];
+    if (mode == 0) {
+        float msum = 0.f;
+        for (int t = 0; t < T; ++t) msum += mask[(size_t)b * T + t];
+        const float dn = d / msum;
+        for (int t = 0; t < T; ++t) {
+            const float p = x[base + (size_t)t * st];
+            dx[base + (size_t)t * st] = dn * mask[(size_t)b * T + t] * (1.f - p * p);
+        }
+    } else {
+        const float mx = s[(size_t)b * F + f];
+        for (int t = 0; t < T; ++t) {
+            const float p = x[base + (size_t)t * st];
+            dx[base + (size_t)t * st] = (p == mx && p > 0.f) ? d : 0.f;
+        }
+    }
+}
+extern "C" int asr_seq_pool_bwd(const float* ds, const float* s, const float* x, size_t sb, size_t st,
+                                const float* mask, int B, int T, int F, int mode, float* dx,
+                                hipStream_t stream) {
+    if (B < 0 || T <= 0 || F <= 0 || !ds || !x || !dx || (mode == 0 && !mask) || (mode == 1 && !s) ||
+        mode < 0 || mode > 1)
+        return ASR_ERR_ARG;
+    if (!B) return ASR_OK;
+    hipLaunchKernelGGL(seq_pool_bwd_kernel, dim3(B, (F + 63) / 64), dim3(64), 0, stream, ds, s, x, sb, st, mask,
+                       T, F, mode, dx);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
 // ------------------------------------------------------------------ gate-major <-> gate-interleaved
 // dir 0: dst[r][u*4+g] = src[r][g*N+u]   (reference stacking -> engine layout);  dir 1: inverse
 __global__ void perm4_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int N,

@@ -1,0 +1,324 @@
+"""The LSTM layer classes of libs/lasagne_libs/recurrent_layers.py (20 classes,
+one variant table, asr_amd/specs.py REC_CLASSES) on the persistent LSTM-family scan kernel.
+
+Per direction the host side prepares, with one kernel each:
+  conditioning prologue  s = pool_t act(src.W_cond + b)  (src = the layer's own input or the external
+                         i-vector input), alpha_in / alpha_hid / beta = s.W + b   (:944-952, :1209-1217)
+  input side             xin = [LN]( x.W_in [+ beta] ) [* alpha_in] [+ beta | + b]  for all T at once
+  recurrent matrix       W' = W_hid_prj . W_hid folded (N x 4N) when the class projects
+and the scan kernel does the rest (asr_amd/csrc/scan_lstm.hip).  Parameter gradients run deferred on
+the side stream; for own-input conditioning the pooled-feature gradient is on the critical path
+because it flows into dX.
+"""
+import ctypes as C
+import torch
+
+from . import _lib, ops, specs
+from .engine import DirParams
+
+G4R = specs.GATES_REC
+
+
+def _mk_rec(store, prefix, cls, D, N, P, F, I):
+    v = specs.REC_CLASSES[cls]
+    dp = DirParams(store, prefix)
+    K = P if P else N
+    dp.add('Wx', (D, 4 * N)); dp.add('Wh', (K, 4 * N))
+    if v['bias']:
+        dp.add('b', (4 * N,))
+    if P:
+        dp.add('Wp', (N, P))
+    if v['ln'] == 'static':
+        dp.add('a_in', (4 * N,)); dp.add('a_hid', (4 * N,))
+        if v['ln_beta']:
+            dp.add('b_in', (4 * N,)); dp.add('b_hid', (4 * N,))
+    if v['cell_ln']:
+        dp.add('a_c', (N,)); dp.add('b_c', (N,))
+    if v['cond']:
+        cin = D if v['cond'] == 'own' else I
+        dp.add('Wc', (cin, F)); dp.add('bc', (F,))
+        for nm in ('ai', 'ah', 'bt'):
+            dp.add('W' + nm, (F, 4 * N))
+        dp.add('bai', (4 * N,)); dp.add('bah', (4 * N,))
+        if not v['bias']:
+            dp.add('bbt', (4 * N,))
+    # reference order / names
+    table = {'W_hid_prj': ('Wp', 'same'), 'W_cond_prj': ('Wc', 'same'), 'b_cond_prj': ('bc', 'same'),
+             'W_alpha_cell': ('a_c', 'same'), 'W_beta_cell': ('b_c', 'same'), 'num_factors': ('b_c', 'same'),
+             'W_beta_in': ('b_in', 'perm4'), 'W_beta_hid': ('b_hid', 'perm4'),
+             'b_alpha_in': ('bai', 'perm4'), 'b_alpha_hid': ('bah', 'perm4'),
+             'W_beta': ('Wbt', 'perm4'), 'b_beta': ('bbt', 'perm4')}
+    for name, shape, _ in specs.rec_params(cls, D, N, F if v['cond'] else (P or None), P or None, I):
+        done = False
+        for g, gn in enumerate(G4R):
+            if name == 'W_in_to_' + gn:
+                dp.map(name, 'Wx', 'gatecols', g); done = True
+            elif name == 'W_hid_to_' + gn:
+                dp.map(name, 'Wh', 'gatecols', g); done = True
+            elif name == 'b_' + gn:
+                dp.map(name, 'b', 'gatevec', g); done = True
+        if done:
+            continue
+        if name == 'W_alpha_in':
+            dp.map(name, 'Wai' if v['cond'] else 'a_in', 'perm4')
+        elif name == 'W_alpha_hid':
+            dp.map(name, 'Wah' if v['cond'] else 'a_hid', 'perm4')
+        else:
+            key, kind = table[name]
+            dp.map(name, key, kind)
+    return dp
+
+
+class RecPair(object):
+    """A forward and optionally a backward direction of one recurrent_layers.py class."""
+    stateful = False
+
+    def __init__(self, net, idx, cls, D, N, clip, ndir, num_factors=None, num_prjs=None, cond_dim=0):
+        v = specs.REC_CLASSES[cls]
+        if v['per_gate']:
+            raise NotImplementedError('asr_amd: per-gate layer norm (%s) is not implemented yet' % cls)
+        self.net = net; self.idx = idx; self.kind = 'rec'; self.cls = cls; self.v = v
+        self.D = D; self.N = N; self.clip = float(clip); self.ndir = ndir
+        self.num_factors = num_factors; self.num_prjs = num_prjs
+        self.P = specs.rec_out_width(cls, N, num_factors, num_prjs)
+        self.F = num_factors if v['cond'] else 0
+        self.I = cond_dim
+        self.out_dim = ndir * (self.P or N)
+        self.ln_kind = {'none': 0, 'static': 1, 'sample': 2}[v['ln']]
+        self.cell_ln = 1 if v['cell_ln'] else 0
+        self.dirs = [_mk_rec(net.store, 'L%d.%d.' % (idx, d), cls, D, N, self.P, self.F, cond_dim)
+                     for d in range(ndir)]
+        self.reverse = [False, True][:ndir]
+
+    def spec_per_dir(self):
+        v = self.v
+        return specs.rec_params(self.cls, self.D, self.N, self.F if v['cond'] else (self.P or None),
+                                self.P or None, self.I)
+
+    def describe(self):
+        out = {}
+        for d, nm in enumerate(('fwd', 'bwd')):
+            if d >= self.ndir:
+                out[nm] = None
+                continue
+            out[nm] = dict(kind='rec', args=dict(variant=dict(self.v), num_units=self.N, out_width=self.P,
+                                                grad_clipping=self.clip, backwards=self.reverse[d],
+                                                cls=self.cls),
+                           params=[r[0] for r in self.dirs[d].refmap])
+        return out
+
+    def get_sample_feat(self, d=0):
+        """recurrent_layers.py:1337-1338 (pooled conditioning feature of the last forward)."""
+        return self.ctx['d'][d]['s']
+
+    def _buf(self, name, rows, cols):
+        return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols)
+
+    # ---------------------------------------------------------------------------------------------
+    def _cond_fwd(self, d, dp, c, X, T, B, mask, cond):
+        v = self.v; F = self.F; N = self.N
+        if v['cond'] == 'own':
+            src = X; rows = T * B; sb, st, Tc = F, B * F, T
+        else:
+            Tc = cond.shape[1]
+            src = cond.view(B * Tc, self.I); rows = B * Tc; sb, st = Tc * F, F
+        mode = 0 if v['pool'] == 'mean_tanh' else 1
+        pre = self._buf('pre%d' % d, rows, F)
+        ops.gemm(src, dp.p('Wc'), pre)
+        ops.bias_act(pre, dp.p('bc'), rows, F, 2 if mode == 0 else 1)
+        s = self._buf('s%d' % d, B, F)
+        ops.seq_pool_fwd(pre, sb, st, mask, B, Tc, F, mode, s)
+        al_in = self._buf('al_in%d' % d, B, 4 * N); al_hid = self._buf('al_hid%d' % d, B, 4 * N)
+        bt = self._buf('bt%d' % d, B, 4 * N)
+        ops.gemm(s, dp.p('Wai'), al_in, bias=dp.p('bai'))
+        ops.gemm(s, dp.p('Wah'), al_hid, bias=dp.p('bah'))
+        ops.gemm(s, dp.p('Wbt'), bt, bias=dp.p('b') if v['bias'] else dp.p('bbt'))
+        c.update(src=src, pre=pre, s=s, al_in=al_in, al_hid=al_hid, bt=bt, pool=(sb, st, Tc, mode))
+
+    def forward(self, X, T, B, mask, cond, train):
+        net = self.net; N = self.N; P = self.P; v = self.v; rows = T * B
+        Pout = P or N
+        Y = self._buf('Y', rows, self.out_dim)
+        desc = _lib.LstmScanDesc()
+        desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
+        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, cond=cond, Y=Y, d=[])
+        L = _lib.lib()
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            if v['cond']:
+                self._cond_fwd(d, dp, c, X, T, B, mask, cond)
+            xin = self._buf('xin%d' % d, rows, 4 * N)
+            if self.ln_kind == 0:
+                ops.gemm(X, dp.p('Wx'), xin, bias=dp.p('b'))
+            else:
+                ops.gemm(X, dp.p('Wx'), xin)
+                xh = self._buf('xhat_in%d' % d, rows, 4 * N); rs = self._buf('rs_in%d' % d, rows, 1)
+                if self.ln_kind == 1:
+                    ops.ln_rows_fwd(xin, 4 * N, dp.p('a_in'), xin, beta=dp.p('b_in') if v['ln_beta'] else None,
+                                    bias=dp.p('b'), xhat=xh, rstd=rs)
+                elif v['beta'] == 'pre':
+                    ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, pre=c['bt'], pmod=B, amod=B, xhat=xh, rstd=rs)
+                else:
+                    ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, beta=c['bt'], amod=B, xhat=xh, rstd=rs)
+                c.update(xhat_in=xh, rs_in=rs)
+            if P:
+                Wf = self._buf('Wf%d' % d, N, 4 * N)
+                ops.gemm(dp.p('Wp'), dp.p('Wh'), Wf)
+            else:
+                Wf = dp.p('Wh')
+            c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d), L.asr_lstm_pack_floats(N, 0)))
+            if train:
+                c['wpkb'] = ops.lstm_pack(Wf, N, 1, net.arena.get('L%d.wpkb%d' % (self.idx, d),
+                                                                  L.asr_lstm_pack_floats(N, 1)))
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            Dd.xin = xin.data_ptr(); Dd.wpack = c['wpk'].data_ptr()
+            if self.ln_kind == 1:
+                Dd.alpha_hid = dp.p('a_hid').data_ptr()
+                Dd.beta_hid = dp.p('b_hid').data_ptr() if v['ln_beta'] else None
+            elif self.ln_kind == 2:
+                Dd.alpha_hid = c['al_hid'].data_ptr()
+            if self.cell_ln:
+                Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
+            R = self._buf('R%d' % d, rows, N) if P else Y[:, d * N:(d + 1) * N]
+            c['R'] = R
+            Dd.r_out = R.data_ptr(); Dd.ld_r = R.stride(0)
+            c['cst'] = self._buf('cst%d' % d, rows, N); Dd.cst = c['cst'].data_ptr()
+            if train:
+                c['gates'] = self._buf('gates%d' % d, rows, 4 * N); Dd.gates = c['gates'].data_ptr()
+            if self.ln_kind:
+                c['ahat'] = self._buf('ahat%d' % d, rows, 4 * N); c['rs_a'] = self._buf('rs_a%d' % d, rows, 1)
+                Dd.ahat = c['ahat'].data_ptr(); Dd.rs_a = c['rs_a'].data_ptr()
+            if self.cell_ln:
+                c['chat'] = self._buf('chat%d' % d, rows, N); c['rs_c'] = self._buf('rs_c%d' % d, rows, 1)
+                Dd.chat = c['chat'].data_ptr(); Dd.rs_c = c['rs_c'].data_ptr()
+            ctx['d'].append(c)
+        net.scan_lstm(self, desc, backward=False)
+        if P:
+            for d, dp in enumerate(self.dirs):
+                ops.gemm(ctx['d'][d]['R'], dp.p('Wp'), Y[:, d * Pout:(d + 1) * Pout])
+        return Y
+
+    # ---------------------------------------------------------------------------------------------
+    def backward(self, dY, need_dx=True):
+        net = self.net; ctx = self.ctx; N = self.N; P = self.P; v = self.v
+        X, T, B, mask = ctx['X'], ctx['T'], ctx['B'], ctx['mask']
+        rows = T * B
+        Pout = P or N
+        later = []
+        desc = _lib.LstmScanDesc()
+        desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
+        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            dYd = dY[:, d * Pout:(d + 1) * Pout]
+            if P:
+                dR = self._buf('dR%d' % d, rows, N)
+                ops.gemm(dYd, dp.p('Wp'), dR, tb=True)
+                later.append(lambda dp=dp, c=c, dYd=dYd: ops.gemm(c['R'], dYd, dp.g('Wp'), ta=True))
+            else:
+                dR = dYd
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            Dd.wpack = c['wpkb'].data_ptr()
+            if self.ln_kind == 1:
+                Dd.alpha_hid = dp.p('a_hid').data_ptr()
+            elif self.ln_kind == 2:
+                Dd.alpha_hid = c['al_hid'].data_ptr()
+            if self.cell_ln:
+                Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
+            Dd.gates = c['gates'].data_ptr(); Dd.cst = c['cst'].data_ptr()
+            if self.ln_kind:
+                Dd.ahat = c['ahat'].data_ptr(); Dd.rs_a = c['rs_a'].data_ptr()
+                c['dA'] = self._buf('dA%d' % d, rows, 4 * N); Dd.dA = c['dA'].data_ptr()
+            if self.cell_ln:
+                Dd.chat = c['chat'].data_ptr(); Dd.rs_c = c['rs_c'].data_ptr()
+                c['dOut'] = self._buf('dOut%d' % d, rows, N); Dd.dOut = c['dOut'].data_ptr()
+            Dd.dr_ext = dR.data_ptr(); Dd.ld_dr = dR.stride(0)
+            c['dG'] = self._buf('dG%d' % d, rows, 4 * N); Dd.dG = c['dG'].data_ptr()
+        net.scan_lstm(self, desc, backward=True)
+        own = v['cond'] == 'own'
+        dX = self._buf('dX', rows, self.D) if (need_dx or False) else None
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            dG = c['dG']
+            if self.ln_kind == 0:
+                dXp = dG
+            else:
+                dXp = self._buf('dXp%d' % d, rows, 4 * N)
+                al = dp.p('a_in') if self.ln_kind == 1 else c['al_in']
+                ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], al, dXp, amod=0 if self.ln_kind == 1 else B)
+            c['dXp'] = dXp
+            if need_dx:
+                ops.gemm(dXp, dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+            if v['cond']:
+                if own and need_dx:        # the pooled-feature gradient flows into dX: critical path
+                    self._cond_bwd(d, dp, c, rows, B)
+                    ops.gemm(c['dpre'], dp.p('Wc'), dX, tb=True, beta=1.0)
+                    later.append(lambda d=d, dp=dp, c=c: self._cond_param_grads(d, dp, c, B))
+                else:
+                    later.append(lambda d=d, dp=dp, c=c: (self._cond_bwd(d, dp, c, rows, B),
+                                                          self._cond_param_grads(d, dp, c, B)))
+            later.append(lambda d=d, dp=dp, c=c: self._param_grads(d, dp, c, X, rows, T, B))
+        with net.deferred():
+            for fn in later:
+                fn()
+        return dX
+
+    def _cond_bwd(self, d, dp, c, rows, B):
+        """d alpha_in, d alpha_hid, d beta (B,4N) -> d s (B,F) -> d pre (layout of pre)."""
+        N = self.N; F = self.F; v = self.v
+        dG = c['dG']
+        dal_in = self._buf('dal_in%d' % d, B, 4 * N); dal_hid = self._buf('dal_hid%d' % d, B, 4 * N)
+        dbt = self._buf('dbt%d' % d, B, 4 * N)
+        ops.colreduce(dG, dal_in, rows, 4 * N, y=c['xhat_in'], gmod=B)
+        ops.colreduce(dG, dal_hid, rows, 4 * N, y=c['ahat'], gmod=B)
+        ops.colreduce(c['dXp'] if v['beta'] == 'pre' else dG, dbt, rows, 4 * N, gmod=B)
+        ds = self._buf('ds%d' % d, B, F)
+        for k, (nm, dv) in enumerate((('ai', dal_in), ('ah', dal_hid), ('bt', dbt))):
+            ops.gemm(dv, dp.p('W' + nm), ds, tb=True, beta=0.0 if k == 0 else 1.0)
+        sb, st, Tc, mode = c['pool']
+        dpre = self._buf('dpre%d' % d, c['pre'].shape[0], F)
+        ops.seq_pool_bwd(ds, c['s'], c['pre'], sb, st, self.ctx['mask'], B, Tc, F, mode, dpre)
+        c.update(dal_in=dal_in, dal_hid=dal_hid, dbt=dbt, dpre=dpre)
+
+    def _cond_param_grads(self, d, dp, c, B):
+        N = self.N; F = self.F; v = self.v
+        s = c['s']
+        for nm, dv in (('ai', c['dal_in']), ('ah', c['dal_hid']), ('bt', c['dbt'])):
+            ops.gemm(s, dv, dp.g('W' + nm), ta=True)
+        ops.colreduce(c['dal_in'], dp.g('bai'), B, 4 * N)
+        ops.colreduce(c['dal_hid'], dp.g('bah'), B, 4 * N)
+        ops.colreduce(c['dbt'], dp.g('b') if v['bias'] else dp.g('bbt'), B, 4 * N)
+        ops.gemm(c['src'], c['dpre'], dp.g('Wc'), ta=True)
+        ops.colreduce(c['dpre'], dp.g('bc'), c['dpre'].shape[0], F)
+
+    def _param_grads(self, d, dp, c, X, rows, T, B):
+        N = self.N; P = self.P; v = self.v
+        dG = c['dG']; dA = c['dA'] if self.ln_kind else dG
+        R = c['R']
+        dWf = self._buf('dWf%d' % d, N, 4 * N) if P else dp.g('Wh')
+        n1 = (T - 1) * B
+        if not self.reverse[d]:
+            Ra, dAb = R[:n1], dA[B:]
+        else:
+            Ra, dAb = R[B:], dA[:n1]
+        ops.gemm(Ra, dAb, dWf, ta=True)
+        if P:
+            ops.gemm(dp.p('Wp'), dWf, dp.g('Wh'), ta=True)
+            ops.gemm(dWf, dp.p('Wh'), dp.g('Wp'), tb=True, beta=1.0)
+        if v['bias'] and not v['cond']:
+            ops.colreduce(dG, dp.g('b'), rows, 4 * N)
+        if self.cell_ln:
+            ops.colreduce(c['dOut'], dp.g('a_c'), rows, N, y=c['chat'])
+            ops.colreduce(c['dOut'], dp.g('b_c'), rows, N)
+        if self.ln_kind == 1:
+            ops.colreduce(dG, dp.g('a_in'), rows, 4 * N, y=c['xhat_in'])
+            ops.colreduce(dG, dp.g('a_hid'), rows, 4 * N, y=c['ahat'])
+            if v['ln_beta']:
+                ops.colreduce(dG, dp.g('b_in'), rows, 4 * N)
+                ops.colreduce(dG, dp.g('b_hid'), rows, 4 * N)
+        ops.gemm(X, c['dXp'], dp.g('Wx'), ta=True)

@@ -66,3 +66,196 @@ def deep_projection_ivector_ln_model(input_var, cond_var, mask_var, num_inputs, 
         D = pair.out_dim
     net.set_output(D, num_outputs, 'logits')
     return net.finalize(seed), cond_layers
+
+
+# ------------------------------------------------------------------------------------------------
+# The remaining LSTM builders of models/gating_hyper_nets.py on the generic recurrent_layers.py
+# family (asr_amd/engine_rec.py).  Same names / argument order / defaults except `dropout`, whose
+# reference default 0.2 is only usable at inference (deterministic=True): training needs dropout=0.
+class CondLayerHandle(object):
+    """What the reference appends to cond_layer_list: one entry per direction with get_sample_feat()
+    (libs/lasagne_libs/recurrent_layers.py:1337-1338)."""
+    def __init__(self, pair, d):
+        self.pair = pair; self.d = d
+
+    def get_sample_feat(self):
+        return self.pair.get_sample_feat(self.d)
+
+
+def _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, plain_cls,
+               cond_cls=None, num_conds=0, num_factors=None, num_prjs=None, cond_dim=0, is_bidir=True,
+               device=None, seed=0, training_dropout_ok=False):
+    from .engine_rec import RecPair
+    net = Network(device or 'cuda:0')
+    net.dropout = dropout
+    ndir = 2 if is_bidir else 1
+    if cond_cls and specs.REC_CLASSES[cond_cls]['cond'] == 'ext':
+        net.uses_cond = True
+    D = num_inputs
+    cond_layers = []
+    for l in range(num_layers):
+        cls = cond_cls if (cond_cls and l < num_conds) else plain_cls
+        pair = RecPair(net, len(net.pairs), cls, D, num_units, grad_clipping, ndir, num_factors=num_factors,
+                       num_prjs=num_prjs, cond_dim=cond_dim)
+        net.add_pair(pair, [pair.spec_per_dir()] * ndir)
+        if cls == cond_cls:
+            cond_layers += [CondLayerHandle(pair, d) for d in range(ndir)]
+        D = pair.out_dim
+    net.set_output(D, num_outputs, 'logits')
+    net.finalize(seed)
+    return net, cond_layers
+
+
+def deep_projection_cond_ln_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_conds,
+                                  num_factors, num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """models/gating_hyper_nets.py:309-382 -> (output_layer, cond_layer_list)."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'ProjectLSTMLayer',
+                      'CondLayerNormProjectLSTMLayer', num_conds, num_factors, device=device, seed=seed)
+
+
+def deep_projection_max_cond_ln_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_conds,
+                                      num_factors, num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """:544-617."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'ProjectLSTMLayer',
+                      'MaxCondLayerNormProjectLSTMLayer', num_conds, num_factors, device=device, seed=seed)
+
+
+def deep_projection_max_ivector_ln_model(input_var, cond_var, mask_var, num_inputs, num_outputs, num_layers,
+                                         num_conds, num_factors, num_units, grad_clipping=1, dropout=0.0,
+                                         cond_dim=100, device=None, seed=0):
+    """:694-772 (i-vector input hard-wired to 100 dims at :710; `cond_dim` exposes it)."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'ProjectLSTMLayer',
+                      'MaxInputCondLayerNormProjectLSTMLayer', num_conds, num_factors, cond_dim=cond_dim,
+                      device=device, seed=seed)
+
+
+def deep_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
+                    dropout=0.0, device=None, seed=0):
+    """:858-906."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LSTMLayer',
+                      device=device, seed=seed)[0]
+
+
+def deep_ln_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
+                       dropout=0.0, device=None, seed=0):
+    """:908-956."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LayerNormLSTMLayer',
+                      device=device, seed=seed)[0]
+
+
+def deep_cond_ln_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_factors, num_conds,
+                       num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """:958-1029 (note the reference's argument order: num_factors BEFORE num_conds)."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LSTMLayer',
+                      'CondLayerNormLSTMLayer', num_conds, num_factors, device=device, seed=seed)
+
+
+def deep_ivector_ln_model(input_var, cond_var, mask_var, num_inputs, num_outputs, num_layers, num_conds,
+                          num_factors, num_units, grad_clipping=1, dropout=0.0, cond_dim=100, device=None, seed=0):
+    """:1031-1107."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LSTMLayer',
+                      'InputCondLayerNormLSTMLayer', num_conds, num_factors, cond_dim=cond_dim, device=device,
+                      seed=seed)
+
+
+def deep_prj_lstm_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, num_prjs,
+                           grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """:1113-1164."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'ProjectLSTM_v0_1_Layer', num_prjs=num_prjs, device=device, seed=seed)[0]
+
+
+def deep_prj_lstm_ln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, num_prjs,
+                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """:1166-1217."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormProjectLSTM_v0_1_Layer', num_prjs=num_prjs, device=device, seed=seed)[0]
+
+
+def deep_prj_lstm_ln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, num_prjs,
+                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """:1219-1270 (per-gate layer norm)."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormProjectLSTM_v0_2_Layer', num_prjs=num_prjs, device=device, seed=seed)[0]
+
+
+def _dln(num_layers, num_conds):
+    return num_layers if num_conds == -1 else num_conds
+
+
+def deep_prj_lstm_dln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_units, num_prjs, num_factors,
+                               num_layers, num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+    """:1272-1352."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormProjectLSTM_v0_1_Layer', 'CondLayerNormProjectLSTM_v0_1_Layer',
+                      _dln(num_layers, num_conds), num_factors, num_prjs, device=device, seed=seed)
+
+
+def deep_prj_lstm_dln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_units, num_prjs, num_factors,
+                               num_layers, num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+    """:1354-1436."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormProjectLSTM_v0_2_Layer', 'CondLayerNormProjectLSTM_v0_2_Layer',
+                      _dln(num_layers, num_conds), num_factors, num_prjs, device=device, seed=seed)
+
+
+def deep_reg_lstm_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
+                           dropout=0.0, device=None, seed=0):
+    """:1438-1486."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'RegularLSTM_v0_1_Layer', device=device, seed=seed)[0]
+
+
+def deep_reg_lstm_ln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units,
+                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """:1488-1536."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormRegularLSTM_v0_1_Layer', device=device, seed=seed)[0]
+
+
+def deep_reg_lstm_ln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units,
+                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+    """:1538-1586 (per-gate layer norm)."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormRegularLSTM_v0_2_Layer', device=device, seed=seed)[0]
+
+
+def deep_reg_lstm_dln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_units, num_factors, num_layers,
+                               num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+    """:1588-1663."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormRegularLSTM_v0_1_Layer', 'CondLayerNormRegularLSTM_v0_1_Layer',
+                      _dln(num_layers, num_conds), num_factors, device=device, seed=seed)
+
+
+def deep_reg_lstm_dln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_units, num_factors, num_layers,
+                               num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+    """:1665-1743."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'LayerNormRegularLSTM_v0_2_Layer', 'CondLayerNormRegularLSTM_v0_2_Layer',
+                      _dln(num_layers, num_conds), num_factors, device=device, seed=seed)
+
+
+def uni_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
+                   dropout=0.0, device=None, seed=0):
+    """:1745-1784 (the only unidirectional builder of the file)."""
+    _check_dropout(dropout)
+    return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
+                      'RegularLSTM_v0_1_Layer', is_bidir=False, device=device, seed=seed)[0]

@@ -103,6 +103,17 @@ def masked_mean_tanh_bwd(ds, mask, pre, B, T, F, dpre):
     return dpre
 
 
+def seq_pool_fwd(x, sb, st, mask, B, T, F, mode, out):
+    check(_lib.lib().asr_seq_pool_fwd(_p(x), sb, st, _p(mask), B, T, F, mode, _p(out), _s()), 'asr_seq_pool_fwd')
+    return out
+
+
+def seq_pool_bwd(ds, s, x, sb, st, mask, B, T, F, mode, dx):
+    check(_lib.lib().asr_seq_pool_bwd(_p(ds), _p(s), _p(x), sb, st, _p(mask), B, T, F, mode, _p(dx), _s()),
+          'asr_seq_pool_bwd')
+    return dx
+
+
 def softmax_ce(logits, C_, B, T, target=None, tmask=None, scale=0.0, dlogits=None, row_ce=None,
                row_ok=None, pred=None, out_mode=0, out=None):
     """target/tmask are the caller's batch-major (B,T) arrays (strides taken from the tensors)."""

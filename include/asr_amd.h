@@ -70,6 +70,15 @@ int asr_masked_mean(const float* x, const float* mask, int B, int T, int F, floa
 int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, const float* pre, int B, int T, int F,
                              float* dpre, asr_stream_t stream);
 
+/* Strided pooling over time of the conditioning prologue (x holds the activated values, element
+ * (b,t,f) at x[b*sb + t*st + f]; mask (B,T) contiguous).  mode 0: masked mean of tanh, libs/lasagne_libs/
+ * recurrent_layers.py:945-946,1210-1211; mode 1: unmasked max of relu, :1469-1470,1734-1735.  The
+ * backward includes the activation derivative and Theano's max gradient (every tied frame). */
+int asr_seq_pool_fwd(const float* x, size_t sb, size_t st, const float* mask, int B, int T, int F, int mode,
+                     float* out, asr_stream_t stream);
+int asr_seq_pool_bwd(const float* ds, const float* s, const float* x, size_t sb, size_t st, const float* mask,
+                     int B, int T, int F, int mode, float* dx, asr_stream_t stream);
+
 /* K3.  Fused log-softmax / CE / argmax / dlogits: libs/comp_graph_utils.py:29-45,
  * scripts/hypernets/exp_prj_ln_lstm_fix.py:84-95, bin/forward_ln_lstmp.py:55-58.
  * out_mode 0 none, 1 log-posteriors, 2 probabilities, written batch-major (B,T,C). */
