@@ -43,8 +43,8 @@ _SIGS = {
     'asr_gemm_f32': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp]),
     'asr_gemm_f32_ws': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
     'asr_swap01': (i32, [fp, fp, i32, i32, i32, i32, i32, fp]),
-    'asr_ln_rows_fwd': (i32, [fp, i32, i32, fp, i32, fp, fp, i32, fp, fp, fp, fp, fp]),
-    'asr_ln_rows_bwd': (i32, [fp, i32, i32, fp, fp, fp, i32, fp, fp]),
+    'asr_ln_rows_fwd': (i32, [fp, i32, i32, fp, i32, fp, fp, i32, fp, fp, fp, fp, i32, fp]),
+    'asr_ln_rows_bwd': (i32, [fp, i32, i32, fp, fp, fp, i32, fp, i32, fp]),
     'asr_colreduce_ws_bytes': (sz, [i32, i32]),
     'asr_colreduce': (i32, [fp, i32, fp, i32, i32, i32, i32, fp, i32, fp, sz, fp]),
     'asr_bias_act': (i32, [fp, fp, i32, i32, i32, fp]),

@@ -41,7 +41,24 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {   // 256 thread
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// sum over the threads of the block whose tid has the same low two bits (= the same gate in the gate-
+// interleaved layout, since the column stride of a thread is 256): sm[16]
+__device__ __forceinline__ float block_sum_gate(float v, float* sm) {
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) < 4) sm[(threadIdx.x >> 6) * 4 + (threadIdx.x & 3)] = v;
+    __syncthreads();
+    const int g = threadIdx.x & 3;
+    return sm[g] + sm[4 + g] + sm[8 + g] + sm[12 + g];
+}
+__device__ __forceinline__ float block_sum_any(float v, float* sm, int groups) {
+    return groups == 4 ? block_sum_gate(v, sm) : block_sum(v, sm);
+}
+
 // ------------------------------------------------------------------ row layer norm, forward
+// groups = 4: gate_ln / sample_gate_ln (recurrent_layers.py:17-25,34-42): the columns of each gate
+// (col & 3 in the interleaved layout) are normalised separately; rstd then holds 4 values per row.
 // y[r,:] = alpha[ra,:] * xhat + beta[ra,:] + bias,  xhat = (x+pre[rp,:] - mean)/sqrt(var+eps)
 // ra = amod ? r % amod : 0 (per-sample alpha/beta when amod = B), rp = r % pmod.
 // x is overwritten in place when y == x.  Saves xhat and rstd for the backward pass.
@@ -51,23 +68,24 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restric
                                                           const float* __restrict__ beta, int amod,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ y, float* __restrict__ xhat,
-                                                          float* __restrict__ rstd) {
-    __shared__ float sm[4];
+                                                          float* __restrict__ rstd, int groups) {
+    __shared__ float sm[16];
     const size_t r = blockIdx.x;
     const float* xr = x + r * n;
     const float* pr = pre ? pre + (size_t)(r % pmod) * n : nullptr;
     const size_t ra = amod ? r % amod : 0;
+    const float ng = (float)(n / groups);
     float s = 0.f;
     for (int c = threadIdx.x; c < n; c += 256) s += xr[c] + (pr ? pr[c] : 0.f);
-    const float mean = block_sum(s, sm) / n;
+    const float mean = block_sum_any(s, sm, groups) / ng;
     float q = 0.f;
     for (int c = threadIdx.x; c < n; c += 256) {
         float d = xr[c] + (pr ? pr[c] : 0.f) - mean;
         q += d * d;
     }
-    const float var = block_sum(q, sm) / n;
+    const float var = block_sum_any(q, sm, groups) / ng;
     const float rs = 1.0f / sqrtf(var + ASR_EPS);
-    if (threadIdx.x == 0 && rstd) rstd[r] = rs;
+    if (rstd && threadIdx.x < groups) rstd[r * groups + threadIdx.x] = rs;
     for (int c = threadIdx.x; c < n; c += 256) {
         float xh = (xr[c] + (pr ? pr[c] : 0.f) - mean) * rs;
         if (xhat) xhat[r * n + c] = xh;
@@ -80,12 +98,12 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restric
 
 extern "C" int asr_ln_rows_fwd(const float* x, int rows, int n, const float* pre, int pmod,
                                const float* alpha, const float* beta, int amod, const float* bias,
-                               float* y, float* xhat, float* rstd, hipStream_t stream) {
-    if (rows < 0 || n <= 0 || !x || !y || !alpha) return ASR_ERR_ARG;
+                               float* y, float* xhat, float* rstd, int groups, hipStream_t stream) {
+    if (rows < 0 || n <= 0 || !x || !y || !alpha || (groups != 1 && groups != 4) || n % groups) return ASR_ERR_ARG;
     if (pre && pmod <= 0) return ASR_ERR_ARG;
     if (rows == 0) return ASR_OK;
     hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(rows), dim3(256), 0, stream, x, n, pre, pmod, alpha,
-                       beta, amod, bias, y, xhat, rstd);
+                       beta, amod, bias, y, xhat, rstd, groups);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
@@ -95,19 +113,20 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
                                                           const float* __restrict__ xhat,
                                                           const float* __restrict__ rstd,
                                                           const float* __restrict__ alpha, int amod,
-                                                          float* __restrict__ dx) {
-    __shared__ float sm[4];
+                                                          float* __restrict__ dx, int groups) {
+    __shared__ float sm[16];
     const size_t r = blockIdx.x;
     const size_t ra = amod ? r % amod : 0;
+    const float ng = (float)(n / groups);
     float s1 = 0.f, s2 = 0.f;
     for (int c = threadIdx.x; c < n; c += 256) {
         float d = dy[r * n + c] * alpha[ra * n + c];
         s1 += d;
         s2 += d * xhat[r * n + c];
     }
-    const float m1 = block_sum(s1, sm) / n;
-    const float m2 = block_sum(s2, sm) / n;
-    const float rs = rstd[r];
+    const float m1 = block_sum_any(s1, sm, groups) / ng;
+    const float m2 = block_sum_any(s2, sm, groups) / ng;
+    const float rs = rstd[r * groups + (groups == 4 ? (threadIdx.x & 3) : 0)];
     for (int c = threadIdx.x; c < n; c += 256) {
         float d = dy[r * n + c] * alpha[ra * n + c];
         dx[r * n + c] = rs * (d - m1 - xhat[r * n + c] * m2);
@@ -115,11 +134,12 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
 }
 
 extern "C" int asr_ln_rows_bwd(const float* dy, int rows, int n, const float* xhat, const float* rstd,
-                               const float* alpha, int amod, float* dx, hipStream_t stream) {
-    if (rows < 0 || n <= 0 || !dy || !xhat || !rstd || !alpha || !dx) return ASR_ERR_ARG;
+                               const float* alpha, int amod, float* dx, int groups, hipStream_t stream) {
+    if (rows < 0 || n <= 0 || !dy || !xhat || !rstd || !alpha || !dx || (groups != 1 && groups != 4) || n % groups)
+        return ASR_ERR_ARG;
     if (rows == 0) return ASR_OK;
     hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(rows), dim3(256), 0, stream, dy, n, xhat, rstd, alpha,
-                       amod, dx);
+                       amod, dx, groups);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

@@ -47,13 +47,14 @@ struct LstmScanArgs {
     int T, B, N, UT, G, KS, KSP, KT;
     int ndir, nchunk, chunk0;
     int ln_kind;             // 0 none, 1 static alpha[,beta], 2 per-sample alpha
+    int per_gate;            // LN statistics per gate (gate_ln / sample_gate_ln) instead of per row
     int cell_ln;
     float clip;
     const float* mask; int msb, mst;
     LstmDir d[2];
     unsigned* sync;          // [ngroups][SYNC_STRIDE]
     float* rex;              // [ngroups][2][KS][64]
-    float* sta;              // [ngroups][2][KS][32]
+    float* sta;              // [ngroups][2][KS][4 gates][32]  (gate 0 only unless per_gate)
     float* stc;              // [ngroups][2][KS][32]
     float* dex;              // [ngroups][2][KS dst][G src][64]      (backward)
 };
@@ -106,7 +107,7 @@ extern "C" int asr_lstm_pack_w(const float* W, int N, int mode, float* out, hipS
 // Combine per-tile (mean, M2) statistics (equal counts cnt per tile) into the row mean / rstd over
 // all KS tiles.  Called by a whole epilogue wave; lane (q,bl) returns the stats of batch row bl.
 __device__ __forceinline__ void combine_stats(const float* st, int KS, int lane, float cnt,
-                                              float& mean, float& rstd) {
+                                              float& mean, float& rstd, int tstride = 32) {
     const int q = lane >> 4, bl = lane & 15;
     float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
     for (int s0 = q; s0 < KS; s0 += 32) {
@@ -114,7 +115,7 @@ __device__ __forceinline__ void combine_stats(const float* st, int KS, int lane,
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             mj[i] = 0.f; M2j[i] = 0.f;
-            if (s0 + 4 * i < KS) ld_sc1_f2(st + (s0 + 4 * i) * 32 + bl * 2, mj[i], M2j[i]);
+            if (s0 + 4 * i < KS) ld_sc1_f2(st + (size_t)(s0 + 4 * i) * tstride + bl * 2, mj[i], M2j[i]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { sm += mj[i]; sm2 += mj[i] * mj[i]; sM2 += M2j[i]; }
@@ -127,7 +128,8 @@ __device__ __forceinline__ void combine_stats(const float* st, int KS, int lane,
     rstd = 1.0f / sqrtf(var + ASR_EPS);
 }
 // plain sums (backward LN: sum dxh, sum dxh*xhat) over all tiles
-__device__ __forceinline__ void combine_sums(const float* st, int KS, int lane, float& s1, float& s2) {
+__device__ __forceinline__ void combine_sums(const float* st, int KS, int lane, float& s1, float& s2,
+                                             int tstride = 32) {
     const int q = lane >> 4, bl = lane & 15;
     float a = 0.f, b = 0.f;
     for (int s0 = q; s0 < KS; s0 += 32) {
@@ -135,7 +137,7 @@ __device__ __forceinline__ void combine_sums(const float* st, int KS, int lane, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             x[i] = 0.f; y[i] = 0.f;
-            if (s0 + 4 * i < KS) ld_sc1_f2(st + (s0 + 4 * i) * 32 + bl * 2, x[i], y[i]);
+            if (s0 + 4 * i < KS) ld_sc1_f2(st + (size_t)(s0 + 4 * i) * tstride + bl * 2, x[i], y[i]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { a += x[i]; b += y[i]; }
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         for (int i = tid; i < UT * KSP * 16; i += 256) dst[i] = src[i];
     }
     float* rex = A.rex + (size_t)grp * 2 * KS * 64;
-    float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 32 : nullptr;
+    float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 128 : nullptr;
     float* stc = A.stc ? A.stc + (size_t)grp * 2 * KS * 32 : nullptr;
     const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(2 * KS * 64 * 4));
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -243,20 +245,45 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
             for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(wave * 4 + w) * 64 + lane) * 4);
         }
         float rs_a = 0.f;
+        f32x4 rs_a4 = {0, 0, 0, 0};
         f32x4 ah4 = {0, 0, 0, 0};
-        if (A.ln_kind) {
+        if (A.ln_kind && !A.per_gate) {
             if (wave < UT) {       // per-tile mean / M2 over its 16 columns, per batch row
                 const float mj = sum_q(a4[0] + a4[1] + a4[2] + a4[3]) * (1.0f / 16.0f);
                 f32x4 dlt = a4 - mj;
                 const float M2 = sum_q(dlt[0] * dlt[0] + dlt[1] * dlt[1] + dlt[2] * dlt[2] + dlt[3] * dlt[3]);
-                if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 32 + bl * 2, mj, M2);
+                if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 128 + bl * 2, mj, M2);
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
             if (wave < UT) {
                 float mean;
-                combine_stats(sta + (size_t)par * KS * 32, KS, lane, 16.0f, mean, rs_a);
+                combine_stats(sta + (size_t)par * KS * 128, KS, lane, 16.0f, mean, rs_a, 128);
                 ah4 = (a4 - mean) * rs_a;
+            }
+        } else if (A.ln_kind) {    // gate_ln: each gate's N columns are normalised on their own;
+            if (wave < UT) {       // per tile and gate: mean / M2 over the tile's 4 units
+                f32x4 mj4, M24;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    mj4[g] = sum_q(a4[g]) * 0.25f;
+                    const float dl = a4[g] - mj4[g];
+                    M24[g] = sum_q(dl * dl);
+                }
+                const float mjq = q == 0 ? mj4[0] : q == 1 ? mj4[1] : q == 2 ? mj4[2] : mj4[3];
+                const float M2q = q == 0 ? M24[0] : q == 1 ? M24[1] : q == 2 ? M24[2] : M24[3];
+                st_sc1_f2(sta + (((size_t)par * KS + tile) * 4 + q) * 32 + bl * 2, mjq, M2q);   // lane q: gate q
+            }
+            group_publish(gs);
+            if (!group_wait(gs)) break;
+            if (wave < UT) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float mean, rs;
+                    combine_stats(sta + (size_t)par * KS * 128 + g * 32, KS, lane, 4.0f, mean, rs, 128);
+                    ah4[g] = (a4[g] - mean) * rs;
+                    rs_a4[g] = rs;
+                }
             }
         }
         float chat_v = 0.f, rs_c = 0.f, c_new = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
@@ -300,7 +327,10 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
                 if (D.gates) *(f32x4*)(D.gates + row * 4 * N + col4) = f32x4{ig, fg, gg, og};
                 if (A.ln_kind && D.ahat) {
                     *(f32x4*)(D.ahat + row * 4 * N + col4) = ah4;
-                    if (tile == 0 && q == 0) D.rs_a[row] = rs_a;
+                    if (tile == 0 && q == 0) {
+                        if (A.per_gate) *(f32x4*)(D.rs_a + row * 4) = rs_a4;
+                        else D.rs_a[row] = rs_a;
+                    }
                 }
                 if (A.cell_ln && D.chat) {
                     D.chat[row * N + unit] = chat_v;
@@ -343,7 +373,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
         for (int i = tid; i < UT * KT * 64; i += 256) dst[i] = src[i];
     }
     float* dex = A.dex + (size_t)grp * 2 * KS * G * 64;
-    float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 32 : nullptr;
+    float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 128 : nullptr;
     float* stc = A.stc ? A.stc + (size_t)grp * 2 * KS * 32 : nullptr;
     const __amdgpu_buffer_rsrc_t dex_rs = make_rsrc_(dex, (unsigned)((size_t)2 * KS * G * 64 * 4));
 
@@ -362,7 +392,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
         const int par = step & 1;
         const size_t row = (size_t)t * B + b;
         const size_t rowp = (size_t)tprev * B + b;
-        f32x4 g4 = {0, 0, 0, 0}, ah4 = {0, 0, 0, 0};
+        f32x4 g4 = {0, 0, 0, 0}, ah4 = {0, 0, 0, 0}, rs_a4 = {0, 0, 0, 0};
         float m = 0.f, c_new = 0.f, c_prev = 0.f, dre = 0.f, chat_v = 0.f, rs_a = 0.f, rs_c = 0.f;
         if (wave < UT && bvalid) {
             m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
@@ -370,7 +400,11 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             c_new = D.cst[row * N + unit];
             c_prev = st > 0 ? D.cst[rowp * N + unit] : (D.c0 ? D.c0[(size_t)b * N + unit] : 0.f);
             dre = D.dr_ext[row * D.ld_dr + unit];
-            if (A.ln_kind) { ah4 = *(const f32x4*)(D.ahat + row * 4 * N + col4); rs_a = D.rs_a[row]; }
+            if (A.ln_kind) {
+                ah4 = *(const f32x4*)(D.ahat + row * 4 * N + col4);
+                if (A.per_gate) rs_a4 = *(const f32x4*)(D.rs_a + row * 4);
+                else rs_a = D.rs_a[row];
+            }
             if (A.cell_ln) { chat_v = D.chat[row * N + unit]; rs_c = D.rs_c[row]; }
         }
         // 1. gather dr contributions published by the previous backward step
@@ -449,17 +483,35 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             if (wave < UT) {
                 const float* al = D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4;
                 dah = dg4 * (*(const f32x4*)al);
-                const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
-                const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
-                if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 32 + bl * 2, s1, s2);
+                if (!A.per_gate) {
+                    const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
+                    const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
+                    if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 128 + bl * 2, s1, s2);
+                } else {
+                    f32x4 s14, s24;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { s14[g] = sum_q(dah[g]); s24[g] = sum_q(dah[g] * ah4[g]); }
+                    const float s1q = q == 0 ? s14[0] : q == 1 ? s14[1] : q == 2 ? s14[2] : s14[3];
+                    const float s2q = q == 0 ? s24[0] : q == 1 ? s24[1] : q == 2 ? s24[2] : s24[3];
+                    st_sc1_f2(sta + (((size_t)par * KS + tile) * 4 + q) * 32 + bl * 2, s1q, s2q);
+                }
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
             if (wave < UT) {
-                float s1, s2;
-                combine_sums(sta + (size_t)par * KS * 32, KS, lane, s1, s2);
-                const float m1 = s1 / (4 * N), m2 = s2 / (4 * N);
-                da4 = rs_a * (dah - m1 - ah4 * m2);
+                if (!A.per_gate) {
+                    float s1, s2;
+                    combine_sums(sta + (size_t)par * KS * 128, KS, lane, s1, s2, 128);
+                    const float m1 = s1 / (4 * N), m2 = s2 / (4 * N);
+                    da4 = rs_a * (dah - m1 - ah4 * m2);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float s1, s2;
+                        combine_sums(sta + (size_t)par * KS * 128 + g * 32, KS, lane, s1, s2, 128);
+                        da4[g] = rs_a4[g] * (dah[g] - s1 / N - ah4[g] * (s2 / N));
+                    }
+                }
                 if (bvalid) *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
             }
         }
@@ -515,7 +567,7 @@ extern "C" size_t asr_lstm_scan_ws_bytes(int T, int B, int N, int ndir, int back
     const size_t ng = (size_t)ndir * nchunk;
     size_t bytes = ng * SYNC_STRIDE * 4;
     bytes += ng * 2 * KS * 64 * 4;            // rex
-    bytes += 2 * ng * 2 * KS * 32 * 4;        // sta, stc
+    bytes += 5 * ng * 2 * KS * 32 * 4;        // sta (x4 for per-gate LN), stc
     if (backward) bytes += ng * 2 * (size_t)KS * KS * 64 * 4;   // dex (G <= KS)
     return bytes + 1024;
 }
@@ -523,7 +575,8 @@ extern "C" size_t asr_lstm_scan_ws_bytes(int T, int B, int N, int ndir, int back
 static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, int backward,
                             hipStream_t stream) {
     if (!d || !ws) return ASR_ERR_ARG;
-    if (d->T < 0 || d->B <= 0 || d->N <= 0 || (d->N & 3) || d->ndir < 1 || d->ndir > 2) return ASR_ERR_ARG;
+    if (d->T < 0 || d->B <= 0 || d->N <= 0 || (d->N & 3) || d->ndir < 1 || d->ndir > 2 ||
+        d->ln_kind < 0 || d->ln_kind > 4) return ASR_ERR_ARG;
     if (!d->mask) return ASR_ERR_ARG;
     for (int k = 0; k < d->ndir; ++k) {
         const LstmDir& D = d->dir[k];
@@ -542,7 +595,9 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     lstm_dims(d->N, &A.KS, &A.KSP, &A.KT);
     A.ndir = d->ndir;
     const int nchunk_total = (d->B + 15) / 16;
-    A.ln_kind = d->ln_kind; A.cell_ln = d->cell_ln; A.clip = d->grad_clip;
+    A.per_gate = d->ln_kind >= 3 ? 1 : 0;
+    A.ln_kind = d->ln_kind >= 3 ? d->ln_kind - 2 : d->ln_kind;
+    A.cell_ln = d->cell_ln; A.clip = d->grad_clip;
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
     A.d[0] = d->dir[0];
     A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
@@ -562,7 +617,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     const size_t ng = (size_t)d->ndir * nchunk_total;
     A.sync = (unsigned*)p;                         p += ng * SYNC_STRIDE * 4;
     A.rex = (float*)p;                             p += ng * 2 * A.KS * 64 * 4;
-    A.sta = (float*)p;                             p += ng * 2 * A.KS * 32 * 4;
+    A.sta = (float*)p;                             p += ng * 2 * A.KS * 128 * 4;
     A.stc = (float*)p;                             p += ng * 2 * A.KS * 32 * 4;
     A.dex = backward ? (float*)p : nullptr;
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;

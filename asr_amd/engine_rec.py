@@ -75,8 +75,6 @@ class RecPair(object):
 
     def __init__(self, net, idx, cls, D, N, clip, ndir, num_factors=None, num_prjs=None, cond_dim=0):
         v = specs.REC_CLASSES[cls]
-        if v['per_gate']:
-            raise NotImplementedError('asr_amd: per-gate layer norm (%s) is not implemented yet' % cls)
         self.net = net; self.idx = idx; self.kind = 'rec'; self.cls = cls; self.v = v
         self.D = D; self.N = N; self.clip = float(clip); self.ndir = ndir
         self.num_factors = num_factors; self.num_prjs = num_prjs
@@ -84,7 +82,8 @@ class RecPair(object):
         self.F = num_factors if v['cond'] else 0
         self.I = cond_dim
         self.out_dim = ndir * (self.P or N)
-        self.ln_kind = {'none': 0, 'static': 1, 'sample': 2}[v['ln']]
+        self.ln_kind = {'none': 0, 'static': 1, 'sample': 2}[v['ln']]     # how alpha is indexed
+        self.grp = 4 if v['per_gate'] else 1
         self.cell_ln = 1 if v['cell_ln'] else 0
         self.dirs = [_mk_rec(net.store, 'L%d.%d.' % (idx, d), cls, D, N, self.P, self.F, cond_dim)
                      for d in range(ndir)]
@@ -141,7 +140,7 @@ class RecPair(object):
         Y = self._buf('Y', rows, self.out_dim)
         desc = _lib.LstmScanDesc()
         desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
-        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
+        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind + (2 if self.grp == 4 else 0), self.cell_ln, self.clip
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
         self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, cond=cond, Y=Y, d=[])
         L = _lib.lib()
@@ -154,14 +153,16 @@ class RecPair(object):
                 ops.gemm(X, dp.p('Wx'), xin, bias=dp.p('b'))
             else:
                 ops.gemm(X, dp.p('Wx'), xin)
-                xh = self._buf('xhat_in%d' % d, rows, 4 * N); rs = self._buf('rs_in%d' % d, rows, 1)
+                xh = self._buf('xhat_in%d' % d, rows, 4 * N); rs = self._buf('rs_in%d' % d, rows, self.grp)
                 if self.ln_kind == 1:
                     ops.ln_rows_fwd(xin, 4 * N, dp.p('a_in'), xin, beta=dp.p('b_in') if v['ln_beta'] else None,
-                                    bias=dp.p('b'), xhat=xh, rstd=rs)
+                                    bias=dp.p('b'), xhat=xh, rstd=rs, groups=self.grp)
                 elif v['beta'] == 'pre':
-                    ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, pre=c['bt'], pmod=B, amod=B, xhat=xh, rstd=rs)
+                    ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, pre=c['bt'], pmod=B, amod=B, xhat=xh, rstd=rs,
+                                    groups=self.grp)
                 else:
-                    ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, beta=c['bt'], amod=B, xhat=xh, rstd=rs)
+                    ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, beta=c['bt'], amod=B, xhat=xh, rstd=rs,
+                                    groups=self.grp)
                 c.update(xhat_in=xh, rs_in=rs)
             if P:
                 Wf = self._buf('Wf%d' % d, N, 4 * N)
@@ -189,7 +190,7 @@ class RecPair(object):
             if train:
                 c['gates'] = self._buf('gates%d' % d, rows, 4 * N); Dd.gates = c['gates'].data_ptr()
             if self.ln_kind:
-                c['ahat'] = self._buf('ahat%d' % d, rows, 4 * N); c['rs_a'] = self._buf('rs_a%d' % d, rows, 1)
+                c['ahat'] = self._buf('ahat%d' % d, rows, 4 * N); c['rs_a'] = self._buf('rs_a%d' % d, rows, self.grp)
                 Dd.ahat = c['ahat'].data_ptr(); Dd.rs_a = c['rs_a'].data_ptr()
             if self.cell_ln:
                 c['chat'] = self._buf('chat%d' % d, rows, N); c['rs_c'] = self._buf('rs_c%d' % d, rows, 1)
@@ -210,7 +211,7 @@ class RecPair(object):
         later = []
         desc = _lib.LstmScanDesc()
         desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
-        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
+        desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind + (2 if self.grp == 4 else 0), self.cell_ln, self.clip
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
         for d, dp in enumerate(self.dirs):
             c = ctx['d'][d]
@@ -250,7 +251,8 @@ class RecPair(object):
             else:
                 dXp = self._buf('dXp%d' % d, rows, 4 * N)
                 al = dp.p('a_in') if self.ln_kind == 1 else c['al_in']
-                ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], al, dXp, amod=0 if self.ln_kind == 1 else B)
+                ops.ln_rows_bwd(dG, 4 * N, c['xhat_in'], c['rs_in'], al, dXp, amod=0 if self.ln_kind == 1 else B,
+                                groups=self.grp)
             c['dXp'] = dXp
             if need_dx:
                 ops.gemm(dXp, dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)

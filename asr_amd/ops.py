@@ -45,16 +45,17 @@ def swap01(src, dst, A, B, D, ld_src=None, ld_dst=None):
     return dst
 
 
-def ln_rows_fwd(x, n, alpha, y, pre=None, pmod=1, beta=None, amod=0, bias=None, xhat=None, rstd=None):
+def ln_rows_fwd(x, n, alpha, y, pre=None, pmod=1, beta=None, amod=0, bias=None, xhat=None, rstd=None,
+                groups=1):
     rows = x.numel() // n
     check(_lib.lib().asr_ln_rows_fwd(_p(x), rows, n, _p(pre), pmod, _p(alpha), _p(beta), amod, _p(bias),
-                                     _p(y), _p(xhat), _p(rstd), _s()), 'asr_ln_rows_fwd')
+                                     _p(y), _p(xhat), _p(rstd), groups, _s()), 'asr_ln_rows_fwd')
     return y
 
 
-def ln_rows_bwd(dy, n, xhat, rstd, alpha, dx, amod=0):
+def ln_rows_bwd(dy, n, xhat, rstd, alpha, dx, amod=0, groups=1):
     rows = dy.numel() // n
-    check(_lib.lib().asr_ln_rows_bwd(_p(dy), rows, n, _p(xhat), _p(rstd), _p(alpha), amod, _p(dx), _s()),
+    check(_lib.lib().asr_ln_rows_bwd(_p(dy), rows, n, _p(xhat), _p(rstd), _p(alpha), amod, _p(dx), groups, _s()),
           'asr_ln_rows_bwd')
     return dx
 

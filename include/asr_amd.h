@@ -47,12 +47,14 @@ int asr_swap01(const float* src, float* dst, int A, int B, int D, int ld_src, in
                asr_stream_t stream);
 
 /* Row layer norm hoisted out of the recurrence: ln()/sample_ln() of the input-side pre-activation,
- * libs/lhuclstm_layers.py:16-21,77; libs/lasagne_libs/recurrent_layers.py:10-15,27-32,711,1241. */
+ * libs/lhuclstm_layers.py:16-21,77; libs/lasagne_libs/recurrent_layers.py:10-15,27-32,711,1241.
+ * groups = 4: gate_ln()/sample_gate_ln() (:17-25,:34-42), each gate's columns (col & 3) normalised
+ * separately, rstd holds 4 values per row; groups = 1 otherwise. */
 int asr_ln_rows_fwd(const float* x, int rows, int n, const float* pre, int pmod, const float* alpha,
                     const float* beta, int amod, const float* bias, float* y, float* xhat, float* rstd,
-                    asr_stream_t stream);
+                    int groups, asr_stream_t stream);
 int asr_ln_rows_bwd(const float* dy, int rows, int n, const float* xhat, const float* rstd,
-                    const float* alpha, int amod, float* dx, asr_stream_t stream);
+                    const float* alpha, int amod, float* dx, int groups, asr_stream_t stream);
 
 /* Deterministic column reductions = the gradients theano.grad produces for b / alpha / beta vectors. */
 size_t asr_colreduce_ws_bytes(int n, int gmod);
@@ -123,7 +125,8 @@ typedef struct asr_lstm_dir {
 } asr_lstm_dir;
 
 typedef struct asr_lstm_scan_desc {
-    int T, B, N, ndir, ln_kind, cell_ln;   /* ln_kind: 0 none, 1 static, 2 per-sample alpha */
+    int T, B, N, ndir, ln_kind, cell_ln;   /* ln_kind: 0 none, 1 static, 2 per-sample alpha,
+                                            * 3 / 4 = 1 / 2 with per-gate statistics (rs_a is (T,B,4)) */
     float grad_clip;                       /* theano.gradient.grad_clip bound, 0 = off */
     const float* mask; int mask_stride_b, mask_stride_t;
     asr_lstm_dir dir[2];

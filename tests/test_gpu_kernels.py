@@ -46,18 +46,73 @@ def test_ln_rows_and_colreduce():
     ops.ln_rows_fwd(dx, n, torch.from_numpy(al).cuda(), y, pre=torch.from_numpy(pre).cuda(), pmod=B, amod=B,
                     bias=torch.from_numpy(bias).cuda(), xhat=xh, rstd=rs)
     ridx = np.arange(rows) % B
-    yo, (xho, so) = O.ln_fwd(x.astype(np.float64) + pre[ridx], al[ridx].astype(np.float64))
+    yo, cache = O.ln_fwd(x.astype(np.float64) + pre[ridx], al[ridx].astype(np.float64))
     assert relerr(y.cpu().numpy(), yo + bias) < 1e-5
     dy = rng.standard_normal((rows, n)).astype(np.float32)
     ddx = torch.empty_like(dx)
     ops.ln_rows_bwd(torch.from_numpy(dy).cuda(), n, xh, rs, torch.from_numpy(al).cuda(), ddx, amod=B)
-    dxo, dalo, _ = O.ln_bwd(dy.astype(np.float64), al[ridx].astype(np.float64), (xho, so))
+    dxo, dalo, _ = O.ln_bwd(dy.astype(np.float64), al[ridx].astype(np.float64), cache)
     assert relerr(ddx.cpu().numpy(), dxo) < 1e-5
     out = torch.empty(B, n, device='cuda')
     ops.colreduce(torch.from_numpy(dy).cuda(), out, rows, n, y=xh, gmod=B)
     ref = np.zeros((B, n))
     np.add.at(ref, ridx, dalo)
     assert relerr(out.cpu().numpy(), ref) < 1e-5
+
+
+def test_ln_rows_per_gate():
+    """groups=4 (gate_ln / sample_gate_ln): the kernel works on gate-interleaved columns (col = unit*4 +
+    gate), the oracle on the reference's gate-major blocks."""
+    from asr_amd import ops
+    rng = np.random.default_rng(3)
+    rows, N, B = 37, 24, 4
+    n = 4 * N
+    to_il = lambda a: a.reshape(a.shape[0], 4, N).transpose(0, 2, 1).reshape(a.shape[0], n)   # gate-major -> interleaved
+    x = rng.standard_normal((rows, n)) * 2 + 0.3
+    al = rng.standard_normal((B, n)); bt = rng.standard_normal((B, n))
+    ridx = np.arange(rows) % B
+    yo, cache = O.ln_fwd(x, al[ridx], bt[ridx], groups=4)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(to_il(a), dtype=np.float32)).cuda()
+    dx = f(x); y = torch.empty_like(dx); xh = torch.empty_like(dx); rs = torch.empty(rows, 4, device='cuda')
+    ops.ln_rows_fwd(dx, n, f(al), y, beta=f(bt), amod=B, xhat=xh, rstd=rs, groups=4)
+    assert relerr(y.cpu().numpy(), to_il(yo)) < 1e-5
+    assert relerr(1.0 / rs.cpu().numpy(), cache[1][:, :, 0]) < 1e-5
+    dy = rng.standard_normal((rows, n))
+    dxo, _, _ = O.ln_bwd(dy, al[ridx], cache)
+    ddx = torch.empty_like(dx)
+    ops.ln_rows_bwd(f(dy), n, xh, rs, f(al), ddx, amod=B, groups=4)
+    assert relerr(ddx.cpu().numpy(), to_il(dxo)) < 1e-5
+
+
+def test_seq_pool_kernels():
+    from asr_amd import ops
+    rng = np.random.default_rng(4)
+    B, T, F = 5, 11, 70
+    lens = np.array([11, 1, 7, 3, 9])
+    mask = (np.arange(T)[None] < lens[:, None]).astype(np.float32)
+    for mode in (0, 1):
+        a = rng.standard_normal((B, T, F)).astype(np.float32)
+        x = np.tanh(a) if mode == 0 else np.maximum(a, 0)
+        if mode == 1:
+            x[2, 3] = x[2, 5]                                   # ties: every tied frame gets the gradient
+        ds = rng.standard_normal((B, F)).astype(np.float32)
+        if mode == 0:
+            s_ref = (x * mask[:, :, None]).sum(1) / mask.sum(1, keepdims=True)
+            dx_ref = ds[:, None, :] / mask.sum(1)[:, None, None] * mask[:, :, None] * (1 - x ** 2)
+        else:
+            s_ref = x.max(1)
+            dx_ref = ds[:, None, :] * (x == s_ref[:, None, :]) * (x > 0)
+        for layout in ('batch_major', 'time_major'):
+            xm = x if layout == 'batch_major' else np.ascontiguousarray(x.transpose(1, 0, 2))
+            sb, st = (T * F, F) if layout == 'batch_major' else (F, B * F)
+            xt = torch.from_numpy(xm).cuda(); out = torch.empty(B, F, device='cuda')
+            ops.seq_pool_fwd(xt, sb, st, torch.from_numpy(mask).cuda(), B, T, F, mode, out)
+            assert relerr(out.cpu().numpy(), s_ref) < 1e-6
+            dxt = torch.empty_like(xt)
+            ops.seq_pool_bwd(torch.from_numpy(ds).cuda(), out, xt, sb, st, torch.from_numpy(mask).cuda(), B, T, F,
+                             mode, dxt)
+            got = dxt.cpu().numpy() if layout == 'batch_major' else dxt.cpu().numpy().transpose(1, 0, 2)
+            assert relerr(got, dx_ref) < 1e-6
 
 
 def test_softmax_ce_kernel():
