@@ -107,6 +107,55 @@ def _build_lhuc_ivector(input_dim, num_layers, num_units, num_proj_units, output
     return net
 
 
+def _build_lhuc_seqsum(input_dim, num_layers, num_units, num_proj_units, output_dim, num_pred_layers,
+                       num_pred_units, num_seqsum_units, num_seqsum_layers, seqsum_output_dim, grad_clipping,
+                       is_bidir, use_layer_norm, use_ivector_input, ivector_dim, stateful, device, seed):
+    from .engine import SeqSumNet
+    net = _new(device, seed)
+    D = input_dim
+    if use_ivector_input:
+        net.ivector_concat = True; net.uses_cond = True
+        D += ivector_dim
+    net.seqsum = SeqSumNet(net, D, num_seqsum_units, num_seqsum_layers, seqsum_output_dim)
+    top = _stack_lstm(net, 'lhuc', D, num_layers, num_units, num_proj_units, grad_clipping, is_bidir,
+                      use_layer_norm, stateful=stateful, emb_dim=seqsum_output_dim,
+                      num_pred_units=num_pred_units, num_pred_layers=num_pred_layers)
+    net.set_output(top, output_dim, 'softmax')
+    net.finalize(seed)
+    return net
+
+
+def build_deep_lhuclstm_seqsum(layer_name, input_var, mask_var, input_dim, num_layers, num_units,
+                               num_proj_units, output_dim, num_pred_layers, num_pred_units, num_seqsum_units,
+                               num_seqsum_layers, seqsum_output_dim, batch_size, grad_clipping, is_bidir,
+                               use_layer_norm, use_ivector_input, ivector_dim, ivector_var=None, device=None,
+                               seed=0):
+    """libs/deep_lhuclstm_builder.py:8-45 -> (network, speaker_layer).  The speaker embedding is the
+    sequence-summarising network's output (libs/builder_utils.py:48-62), shared by all layers."""
+    net = _build_lhuc_seqsum(input_dim, num_layers, num_units, num_proj_units, output_dim, num_pred_layers,
+                             num_pred_units, num_seqsum_units, num_seqsum_layers, seqsum_output_dim,
+                             grad_clipping, is_bidir, use_layer_norm, use_ivector_input, ivector_dim, False,
+                             device, seed)
+    return net, net.seqsum
+
+
+def build_deep_uni_lhuclstm_seqsum_tbptt(layer_name, input_var, mask_var, input_dim, num_layers, num_units,
+                                         num_proj_units, output_dim, num_pred_layers, num_pred_units,
+                                         num_seqsum_units, num_seqsum_layers, seqsum_output_dim, batch_size,
+                                         grad_clipping, use_layer_norm, use_ivector_input, ivector_dim,
+                                         ivector_var=None, device=None, seed=0):
+    """libs/deep_lhuclstm_builder.py:85-116 -> (network, speaker_layer, tbptt_layers); the summary is
+    taken over each window the network is fed."""
+    net = _build_lhuc_seqsum(input_dim, num_layers, num_units, num_proj_units, output_dim, num_pred_layers,
+                             num_pred_units, num_seqsum_units, num_seqsum_layers, seqsum_output_dim,
+                             grad_clipping, False, use_layer_norm, use_ivector_input, ivector_dim, True,
+                             device, seed)
+    tb = net.tbptt_layers()
+    for l in tb:
+        l.reset(batch_size)
+    return net, net.seqsum, tb
+
+
 def build_deep_lhuclstm_ivector(layer_name, input_var, mask_var, input_dim, num_layers, num_units,
                                 num_proj_units, output_dim, num_pred_layers, num_pred_units,
                                 num_seqsum_units, num_seqsum_layers, seqsum_output_dim, batch_size,

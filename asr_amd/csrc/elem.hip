@@ -308,6 +308,8 @@ extern "C" int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, cons
 // The conditioning prologue of the cond-LN layers pools an activation over time per utterance:
 //   mode 0: masked mean of tanh(.)  (recurrent_layers.py:945-946, :1210-1211)
 //   mode 1: unmasked max of relu(.) (:1469-1470, :1734-1735)
+//   mode 2: masked mean of the values as they are (no activation derivative in the backward): the
+//           SummarizingLayer T.mean(axis=1) of libs/builder_utils.py:5-22 with an all-ones mask
 // x holds the ACTIVATED values, element (b,t,f) at x[b*sb + t*st + f] (time-major own-input pooling:
 // sb = F, st = B*F; batch-major i-vector pooling: sb = T*F, st = F); mask is (B,T) contiguous.
 __global__ void seq_pool_fwd_kernel(const float* __restrict__ x, size_t sb, size_t st,
@@ -317,7 +319,7 @@ __global__ void seq_pool_fwd_kernel(const float* __restrict__ x, size_t sb, size
     const int f = blockIdx.y * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const float* xb = x + (size_t)b * sb + f;
-    if (mode == 0) {
+    if (mode != 1) {
         float acc = 0.f, msum = 0.f;
         for (int t = 0; t < T; ++t) {
             const float m = mask[(size_t)b * T + t];
@@ -333,7 +335,7 @@ __global__ void seq_pool_fwd_kernel(const float* __restrict__ x, size_t sb, size
 }
 extern "C" int asr_seq_pool_fwd(const float* x, size_t sb, size_t st, const float* mask, int B, int T, int F,
                                 int mode, float* out, hipStream_t stream) {
-    if (B < 0 || T <= 0 || F <= 0 || !x || !out || (mode == 0 && !mask) || mode < 0 || mode > 1) return ASR_ERR_ARG;
+    if (B < 0 || T <= 0 || F <= 0 || !x || !out || (mode != 1 && !mask) || mode < 0 || mode > 2) return ASR_ERR_ARG;
     if (!B) return ASR_OK;
     hipLaunchKernelGGL(seq_pool_fwd_kernel, dim3(B, (F + 63) / 64), dim3(64), 0, stream, x, sb, st, mask, T, F,
                        mode, out);
@@ -352,12 +354,12 @@ __global__ void seq_pool_bwd_kernel(const float* __restrict__ ds, const float* _
     if (f >= F) return;
     const size_t base = (size_t)b * sb + f;
     const float d = ds[(size_t)b * F + f];
-    if (mode == 0) {
+    if (mode != 1) {
         float msum = 0.f;
         for (int t = 0; t < T; ++t) msum += mask[(size_t)b * T + t];
         const float dn = d / msum;
         for (int t = 0; t < T; ++t) {
-            const float p = x[base + (size_t)t * st];
+            const float p = mode == 0 ? x[base + (size_t)t * st] : 0.f;
             dx[base + (size_t)t * st] = dn * mask[(size_t)b * T + t] * (1.f - p * p);
         }
     } else {
@@ -371,8 +373,8 @@ __global__ void seq_pool_bwd_kernel(const float* __restrict__ ds, const float* _
 extern "C" int asr_seq_pool_bwd(const float* ds, const float* s, const float* x, size_t sb, size_t st,
                                 const float* mask, int B, int T, int F, int mode, float* dx,
                                 hipStream_t stream) {
-    if (B < 0 || T <= 0 || F <= 0 || !ds || !x || !dx || (mode == 0 && !mask) || (mode == 1 && !s) ||
-        mode < 0 || mode > 1)
+    if (B < 0 || T <= 0 || F <= 0 || !ds || !dx || (mode != 2 && !x) || (mode != 1 && !mask) || (mode == 1 && !s) ||
+        mode < 0 || mode > 2)
         return ASR_ERR_ARG;
     if (!B) return ASR_OK;
     hipLaunchKernelGGL(seq_pool_bwd_kernel, dim3(B, (F + 63) / 64), dim3(64), 0, stream, ds, s, x, sb, st, mask,

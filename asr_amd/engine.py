@@ -367,7 +367,10 @@ class LstmPair(object):
                 else:
                     hid = c['R']
                 c['hid'] = hid
-                emb = cond[:, 0, :].contiguous()            # libs/lhuclstm_layers.py:504-510
+                if net.seqsum is not None:                  # SeqSumLHUCLSTMLayer, :487-489
+                    emb = net.seqsum.emb
+                else:
+                    emb = cond[:, 0, :].contiguous()        # IVectorLHUCLSTMLayer, :504-510
                 acts = [emb]
                 for i in range(self.npl):
                     a = self._buf('lh_a%d_%d' % (i, d), B, self.npu)
@@ -465,6 +468,8 @@ class LstmPair(object):
             ops.gemm(acts[i], dprev, dp.g('We%d' % i), ta=True)
             ops.colreduce(dprev, dp.g('be%d' % i), B, self.npu)
             da = dprev
+        if self.net.seqsum is not None:       # the embedding is a function of the seq-summary parameters
+            self.net.seqsum.accumulate(da, dp.p('We0'))
 
     def _param_grads(self, d, dp, c, X, cond, mask, rows, T, B):
         N = self.N; P = self.P
@@ -534,6 +539,61 @@ def _init_tensor(rng, shape, init):
     return np.full(shape, v, dtype=np.float32)
 
 
+class SeqSumNet(object):
+    """Sequence-summarising speaker network of libs/builder_utils.py:48-62: framewise tanh MLP on the
+    network input, linear output, then SummarizingLayer = UNMASKED T.mean over time (:5-22) -> one
+    embedding per utterance, shared by every SeqSumLHUCLSTMLayer (libs/lhuclstm_layers.py:473-489)."""
+    def __init__(self, net, Din, num_units, num_layers, out_dim):
+        self.net = net
+        self.dims = [Din] + [num_units] * num_layers + [out_dim]
+        self.nl = num_layers
+        self.dp = DirParams(net.store, 'seqsum.')
+        self.spec = []
+        for i in range(num_layers + 1):
+            self.dp.add('W%d' % i, (self.dims[i], self.dims[i + 1])); self.dp.add('b%d' % i, (self.dims[i + 1],))
+            self.dp.map('seqsum_W_%d' % i, 'W%d' % i); self.dp.map('seqsum_b_%d' % i, 'b%d' % i)
+            self.spec += [('seqsum_W_%d' % i, (self.dims[i], self.dims[i + 1]), 'glorot_uniform'),
+                          ('seqsum_b_%d' % i, (self.dims[i + 1],), ('const', 0.0))]
+        self.first = True
+
+    def forward(self, X0, T, B):
+        arena = self.net.arena; dp = self.dp; rows = T * B
+        acts = [X0]
+        for i in range(self.nl + 1):
+            a = arena.mat('seqsum.a%d' % i, rows, self.dims[i + 1])
+            ops.gemm(acts[-1], dp.p('W%d' % i), a)
+            ops.bias_act(a, dp.p('b%d' % i), rows, self.dims[i + 1], 2 if i < self.nl else 0)
+            acts.append(a)
+        E = self.dims[-1]
+        ones = arena.get('seqsum.ones', B * T)
+        ones.fill_(1.0)
+        self.emb = arena.mat('seqsum.emb', B, E)
+        ops.seq_pool_fwd(acts[-1], E, B * E, ones, B, T, E, 2, self.emb)
+        self.acts = acts; self.T, self.B = T, B; self.ones = ones
+        self.demb = arena.mat('seqsum.demb', B, E)
+        self.first = True
+        return self.emb
+
+    def accumulate(self, da, W0):
+        """demb (+)= da . W0^T from one LHUC layer-direction (called in backward order)."""
+        ops.gemm(da, W0, self.demb, tb=True, beta=0.0 if self.first else 1.0)
+        self.first = False
+
+    def backward(self):
+        arena = self.net.arena; dp = self.dp; T, B = self.T, self.B; rows = T * B
+        E = self.dims[-1]
+        d = arena.mat('seqsum.d%d' % self.nl, rows, E)
+        ops.seq_pool_bwd(self.demb, None, None, E, B * E, self.ones, B, T, E, 2, d)
+        for i in range(self.nl, -1, -1):
+            ops.gemm(self.acts[i], d, dp.g('W%d' % i), ta=True)
+            ops.colreduce(d, dp.g('b%d' % i), rows, self.dims[i + 1])
+            if i > 0:
+                dprev = arena.mat('seqsum.d%d' % (i - 1), rows, self.dims[i])
+                ops.gemm(d, dp.p('W%d' % i), dprev, tb=True)
+                ops.act_bwd(dprev, self.acts[i], rows, self.dims[i], 2)
+                d = dprev
+
+
 class Network(object):
     """The stacked model + output layer.  Built by asr_amd.builders / asr_amd.gating_hyper_nets."""
     def __init__(self, device='cuda:0'):
@@ -543,6 +603,7 @@ class Network(object):
         self.pairs = []
         self.pair_specs = []       # per pair: list (per direction) of [(ref_name, shape, init)]
         self.out = None
+        self.seqsum = None           # SeqSumNet (build_deep_lhuclstm_seqsum*)
         self.ivector_concat = False
         self.uses_cond = False
         self.output_mode = 'softmax'      # what ff_fn returns: 'softmax' probabilities or 'logits'
@@ -573,6 +634,9 @@ class Network(object):
     def finalize(self, seed=0):
         self.store.materialize(self.device)
         rng = np.random.default_rng(seed)
+        if self.seqsum is not None:
+            vals = {n: torch.from_numpy(_init_tensor(rng, s, i)).to(self.device) for n, s, i in self.seqsum.spec}
+            self.seqsum.dp.load_ref(vals)
         for pair, sp in zip(self.pairs, self.pair_specs):
             for dp, spec in zip(pair.dirs, sp):
                 vals = {n: torch.from_numpy(_init_tensor(rng, s, i)).to(self.device) for n, s, i in spec}
@@ -589,7 +653,7 @@ class Network(object):
 
     # ---- reference-compatible parameter lists -------------------------------------------------
     def _all_dirparams(self):
-        out = []
+        out = [self.seqsum.dp] if self.seqsum is not None else []   # incomings-first order: SURVEY 8b.3
         for pair in self.pairs:
             out.extend(pair.dirs)
         out.append(self.out)
@@ -644,8 +708,11 @@ class Network(object):
         layers = []
         for pair in self.pairs:
             layers.append(pair.describe())
-        return dict(layers=layers, output=self.output_mode, ivector_concat=self.ivector_concat,
-                    cond=self.uses_cond)
+        d = dict(layers=layers, output=self.output_mode, ivector_concat=self.ivector_concat,
+                 cond=self.uses_cond)
+        if self.seqsum is not None:
+            d['seqsum'] = dict(num_layers=self.seqsum.nl, params=[r[0] for r in self.seqsum.dp.refmap])
+        return d
 
     def tbptt_layers(self):
         return [p for p in self.pairs if getattr(p, 'stateful', False)]
@@ -744,6 +811,8 @@ class Network(object):
             cond = cond.contiguous()
         self.B, self.T = B, T
         act = self._prep_input(x, cond)
+        if self.seqsum is not None:
+            self.seqsum.forward(act, T, B)
         for pair in self.pairs:
             act = pair.forward(act, T, B, mask, cond, train)
         self.top = act
@@ -806,6 +875,11 @@ class Network(object):
             if self.grad_hook:
                 with self.deferred():          # after this layer's (deferred) parameter gradients
                     self.grad_hook(*self.param_range('L%d.' % i))
+        if self.seqsum is not None:
+            with self.deferred():
+                self.seqsum.backward()
+                if self.grad_hook:
+                    self.grad_hook(*self.param_range('seqsum.'))
         self.join_deferred()
 
     def adam_update(self, lr, b1=0.9, b2=0.999, eps=1e-8, want_sqrt=True):

@@ -74,7 +74,8 @@ int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, const float* pr
 
 /* Strided pooling over time of the conditioning prologue (x holds the activated values, element
  * (b,t,f) at x[b*sb + t*st + f]; mask (B,T) contiguous).  mode 0: masked mean of tanh, libs/lasagne_libs/
- * recurrent_layers.py:945-946,1210-1211; mode 1: unmasked max of relu, :1469-1470,1734-1735.  The
+ * recurrent_layers.py:945-946,1210-1211; mode 1: unmasked max of relu, :1469-1470,1734-1735; mode 2:
+ * plain masked mean (SummarizingLayer, libs/builder_utils.py:5-22, with an all-ones mask).  The
  * backward includes the activation derivative and Theano's max gradient (every tied frame). */
 int asr_seq_pool_fwd(const float* x, size_t sb, size_t st, const float* mask, int B, int T, int F, int mode,
                      float* out, asr_stream_t stream);

@@ -411,6 +411,7 @@ class LHUCLSTMLayerO(LSTMLayerO):
             G['W_e_h_%d' % i] = self.acts[i].T @ da
             G['b_e_h_%d' % i] = da.sum(0)
             da = da @ self.P['W_e_h_%d' % i].T
+        self.demb = da                                  # gradient wrt the speaker embedding
         return dx
 
 
@@ -719,6 +720,10 @@ class OracleNetwork(object):
         self.names = []
         self.layers = []
         k = 0
+        self.seqsum = None
+        if desc.get('seqsum'):          # libs/builder_utils.py:48-62: values come first (incomings-first order)
+            n = len(desc['seqsum']['params'])
+            self.seqsum = vals[:n]; k = n
         for L in desc['layers']:
             pair = []
             for d in ('fwd', 'bwd'):
@@ -747,6 +752,14 @@ class OracleNetwork(object):
             x = np.concatenate([x, cond], axis=-1)          # libs/deep_lstm_builder.py:14-16
         self.acts = [x]
         self.split = []
+        if self.seqsum is not None:     # tanh MLP framewise, linear output, UNMASKED mean over time
+            ss = self.seqsum; nl = len(ss) // 2 - 1
+            a = [x]
+            for i in range(nl):
+                a.append(np.tanh(a[-1] @ ss[2 * i] + ss[2 * i + 1]))
+            out = a[-1] @ ss[2 * nl] + ss[2 * nl + 1]
+            self.ss_acts = a
+            cond = out.mean(axis=1)[:, None, :]          # SeqSumLHUCLSTMLayer reads it as the embedding
         for f, b in self.layers:
             yf = f.forward(self.acts[-1], mask, cond)
             self.split.append(yf.shape[-1])
@@ -784,6 +797,19 @@ class OracleNetwork(object):
                                  [b.grads[n] for n in b.param_names])
             dy = dx
         grads = [g for lg_ in reversed(grads_rev) for g in lg_] + [gW, gb]
+        if self.seqsum is not None:
+            ss = self.seqsum; nl = len(ss) // 2 - 1
+            demb = sum(l.demb for pair in self.layers for l in pair if l is not None)
+            a = self.ss_acts
+            Tn = a[0].shape[1]
+            d = np.repeat(demb[:, None, :] / Tn, Tn, axis=1)
+            sg = [None] * len(ss)
+            for i in range(nl, -1, -1):
+                sg[2 * i] = a[i].reshape(-1, a[i].shape[-1]).T @ d.reshape(-1, d.shape[-1])
+                sg[2 * i + 1] = d.sum((0, 1))
+                if i > 0:
+                    d = (d @ ss[2 * i].T) * (1 - a[i] ** 2)
+            grads = sg + grads
         if context:
             pred = pred[:, :context]
         return ce_cost, ce_sum, pred, grads

@@ -299,3 +299,23 @@ def rec_layer(P, cls, x, mask, N, clip=0, backwards=False, cond=None):
     _, hid_out = _scan(step, [inp, m], init, backwards)
     hid_out = hid_out.transpose(0, 1)
     return hid_out.flip(1) if backwards else hid_out
+
+
+def seqsum_lhuc_net(ss, layers, x, mask, N, npl, clip=0):
+    """build_deep_lhuclstm_seqsum wiring (libs/deep_lhuclstm_builder.py:8-45, libs/builder_utils.py:48-62)
+    for unidirectional layers: ss = [W0, b0, ..., W_out, b_out]; layers = list of LHUC layer dicts."""
+    nl = len(ss) // 2 - 1
+    h = x.reshape(-1, x.shape[-1])
+    for i in range(nl):
+        h = torch.tanh(h @ ss[2 * i] + ss[2 * i + 1])
+    h = h @ ss[2 * nl] + ss[2 * nl + 1]
+    emb = h.reshape(x.shape[0], x.shape[1], -1).mean(dim=1)
+    out = x
+    for P in layers:
+        hid = lstm_layer(P, out, mask, N, clip=clip)
+        pred = emb
+        for i in range(npl):
+            pred = torch.relu(pred @ P['W_e_h_%d' % i] + P['b_e_h_%d' % i])
+        sf = pred @ P['W_e_h_%d' % npl] + P['b_e_h_%d' % npl]
+        out = hid * torch.relu(sf).unsqueeze(1)
+    return out

@@ -231,3 +231,48 @@ def test_adam_step_matches_oracle():
         np.testing.assert_allclose(gn, np.sqrt(sum((gi ** 2).sum() for gi in g)), rtol=1e-5)
     for a, o in zip(net.get_all_param_values(), vals):
         assert relerr(a, o) < 1e-5
+
+
+@pytest.mark.parametrize('use_ivector_input', [False, True])
+def test_lhuc_seqsum(use_ivector_input):
+    """build_deep_lhuclstm_seqsum: shared sequence-summarising embedding, bidirectional, projection."""
+    from asr_amd.builders import build_deep_lhuclstm_seqsum
+    net, speaker = build_deep_lhuclstm_seqsum('SeqSumLHUCLSTMLayer', None, None, 5, 2, 8, 4, 6, 1, 5, 7, 1, 4, 3,
+                                              0.05, True, False, use_ivector_input, 3, True, device=_dev(), seed=5)
+    assert speaker is net.seqsum and net.describe()['seqsum']['num_layers'] == 1
+    names = [p.name for p in net.get_all_params()]
+    assert names[0].endswith('seqsum_W_0') and names[3].endswith('seqsum_b_1')     # incomings-first order
+    perturb_params(net, 11, 0.2)
+    b = make_batch(np.random.default_rng(12), 3, 7, 5, 6, I=3)
+    run_case(net, b, cond_key='ivec' if use_ivector_input else None)
+
+
+def test_lhuc_seqsum_tbptt_windows():
+    from asr_amd.builders import build_deep_uni_lhuclstm_seqsum_tbptt
+    ctxt = 3
+    net, speaker, tb = build_deep_uni_lhuclstm_seqsum_tbptt('SeqSumLHUCLSTMLayer', None, None, 5, 2, 8, 0, 6, 1, 5,
+                                                            7, 2, 4, 3, 0.05, False, False, 0, None,
+                                                            device=_dev(), seed=6)
+    assert len(tb) == 2
+    for l in tb:                                  # the reference's tbptt builder sets no context on the layers
+        l.context = ctxt
+    perturb_params(net, 13, 0.2)
+    b = make_batch(np.random.default_rng(14), 3, 8, 5, 6, lengths=[8, 1, 5])
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    for l in tb:
+        l.reset(3)
+    for l in onet.tbptt_layers():
+        l.reset(3)
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    full = (b['x'], b['mask'], b['x'], b['mask'], b['y'], b['mask'])
+    for win in O.gen_win(full, ctxt, 0):
+        xw, mw, _, _, yw, tmw = win
+        ce, ok, pred = net.loss(t(xw), t(mw), t(yw), t(tmw), None, True, ctxt)
+        net.backward()
+        net.check_status()
+        oc, os_, opred, ograds = onet.loss_and_grads(xw, mw, yw, tmw, None, context=ctxt)
+        assert abs(ce.item() - os_) <= 2e-5 * max(abs(os_), 1.0), (ce.item(), os_)
+        gmax = max(np.max(np.abs(g)) for g in ograds)
+        for g, og in zip(net.get_all_grad_values(), ograds):
+            assert np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax) < 1e-4

@@ -151,3 +151,41 @@ def test_finite_difference_hyper():
         Pp[name][idx] += 1e-6; Pm[name][idx] -= 1e-6
         fd = (loss(Pp) - loss(Pm)) / 2e-6
         np.testing.assert_allclose(lay.grads[name][idx], fd, rtol=1e-5, atol=1e-8)
+
+
+def test_seqsum_lhuc_network():
+    """Sequence-summarising speaker network + two SeqSumLHUCLSTMLayers: OracleNetwork (incl. the
+    gradient into the seq-summary parameters through both layers) against torch autograd."""
+    rng = np.random.default_rng(18)
+    E, SU = 4, 5
+    ss_spec = [('seqsum_W_0', (D, SU), 'glorot_uniform'), ('seqsum_b_0', (SU,), ('const', 0.0)),
+               ('seqsum_W_1', (SU, E), 'glorot_uniform'), ('seqsum_b_1', (E,), ('const', 0.0))]
+    ssP = make_params(rng, ss_spec, perturb=0.2)
+    lay_specs = [specs.lhuc_params(D, N, 0, False, E, 5, 1), specs.lhuc_params(N, N, 0, False, E, 5, 1)]
+    layP = [make_params(rng, sp, perturb=0.3) for sp in lay_specs]
+    outP = make_params(rng, specs.dense_params(N, C), perturb=0.1)
+    desc = dict(layers=[dict(fwd=dict(kind='lhuc', args=dict(num_units=N, num_pred_units=5, num_pred_layers=1,
+                                                             grad_clipping=0.4), params=[n for n, _, _ in sp]),
+                             bwd=None) for sp in lay_specs],
+                output='softmax', ivector_concat=False, cond=False,
+                seqsum=dict(num_layers=1, params=[n for n, _, _ in ss_spec]))
+    values = [ssP[n] for n, _, _ in ss_spec] + [P[n] for P, sp in zip(layP, lay_specs) for n, _, _ in sp] + \
+             [outP['W'], outP['b']]
+    b = make_batch(rng, B, T, D, C)
+    onet = O.OracleNetwork(desc, values)
+    _, ce_sum, _, grads = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    tv = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in values]
+    ss_t = tv[:4]
+    k = 4
+    lay_t = []
+    for sp in lay_specs:
+        lay_t.append({n: tv[k + i] for i, (n, _, _) in enumerate(sp)}); k += len(sp)
+    xt = torch.tensor(b['x'], dtype=torch.float64); mt = torch.tensor(b['mask'], dtype=torch.float64)
+    top = R.seqsum_lhuc_net(ss_t, lay_t, xt, mt, N, 1, clip=0.4)
+    lp = torch.log_softmax(top @ tv[-2] + tv[-1], -1)
+    ce = -(lp.gather(2, torch.tensor(b['y'], dtype=torch.int64).unsqueeze(-1))[:, :, 0] * mt)
+    (ce.sum() / B).backward()
+    np.testing.assert_allclose(ce_sum, ce.sum().item(), rtol=1e-10)
+    for g, t in zip(grads, tv):
+        np.testing.assert_allclose(g, t.grad.numpy(), rtol=1e-7, atol=1e-10)
+    assert np.abs(grads[0]).max() > 1e-6          # the embedding path really carries gradient
