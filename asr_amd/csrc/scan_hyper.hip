@@ -38,6 +38,7 @@ struct HyperArgs {
     int T, B, N, H, G, UH, KS, KSP, KT, HS, HSP, HT;
     int ndir, chunk0, rpc;       // rpc = batch rows per chunk/group (8 or 16)
     float clip;
+    float clip_out;              // bound of the extra grad_clip on outcell (ScalingHyperLSTMLayer), 0 = none
     const float* mask; int msb, mst;
     HyperDir d[2];
     unsigned* sync;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                 const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
                 const float tc = tanhf_(c_new);
                 const float do_ = dh_t * tc;
-                const float dct = dc + dh_t * og * (1.f - tc * tc);
+                const float dct = dc + clipf_(dh_t * og * (1.f - tc * tc), A.clip_out);
                 dg4[0] = clipf_(dct * gg * ig * (1.f - ig), A.clip);
                 dg4[1] = clipf_(dct * c_prev * fg * (1.f - fg), A.clip);
                 dg4[2] = clipf_(dct * ig * (1.f - gg * gg), A.clip);
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                 const float hi = hg4[0], hf = hg4[1], hgc = hg4[2], ho = hg4[3];
                 const float thc = tanhf_(hc_new);
                 const float dho = dhh_new * thc;
-                const float dhct = dhc + dhh_new * ho * (1.f - thc * thc);
+                const float dhct = dhc + clipf_(dhh_new * ho * (1.f - thc * thc), A.clip_out);
                 dhg[0] = clipf_(dhct * hgc * hi * (1.f - hi), A.clip);
                 dhg[1] = clipf_(dhct * hc_prev * hf * (1.f - hf), A.clip);
                 dhg[2] = clipf_(dhct * hi * (1.f - hgc * hgc), A.clip);
@@ -700,6 +701,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
 struct asr_hyper_scan_desc {
     int T, B, N, H, ndir;
     float grad_clip;
+    int clip_outcell;
     const float* mask; int mask_stride_b, mask_stride_t;
     HyperDir dir[2];
 };
@@ -739,6 +741,7 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     if (d->T == 0) return ASR_OK;
     if (A.G * d->ndir > 256) return ASR_ERR_ARG;         // co-residency bound of the persistent grid
     A.T = d->T; A.B = d->B; A.ndir = d->ndir; A.clip = d->grad_clip;
+    A.clip_out = d->clip_outcell ? d->grad_clip : 0.f;
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
     A.d[0] = d->dir[0]; A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
     const size_t per_wg = hyper_pack_floats_wg(A, backward);

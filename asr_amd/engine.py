@@ -117,6 +117,8 @@ class DirParams(object):
             return E[arg, :-1, :]
         if kind == 'aug_b':
             return E[arg, -1, :]
+        if kind == 'fn':                         # arg: callable engine tensor -> strided view
+            return arg(E)
         raise KeyError(kind)
 
     def load_ref(self, values, grads=False):

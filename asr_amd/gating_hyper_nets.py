@@ -259,3 +259,37 @@ def uni_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num
     _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'RegularLSTM_v0_1_Layer', is_bidir=False, device=device, seed=seed)[0]
+
+
+def deep_scaling_hyper_model(input_var, mask_var, num_inputs, num_outputs, num_inner_units_list,
+                             num_outer_units_list, use_peepholes=False, use_layer_norm=False, learn_init=False,
+                             grad_clipping=1.0, get_inner_hid=False, use_softmax=True, device=None, seed=0):
+    """models/gating_hyper_nets.py:27-115: bidirectional ScalingHyperLSTMLayer stack; each layer's
+    OUTER hidden sequences (fwd | bwd) feed the next layer and the SequenceDenseLayer.  With
+    get_inner_hid=True the reference returns the inner-hidden slice layers before the output layer;
+    here that is a list of (pair, direction) handles with .get_output() -> (T*B, inner) of the last
+    forward, followed by the Network.  Only the reference defaults use_peepholes=False /
+    use_layer_norm=False / learn_init=False are on the HIP path."""
+    if use_peepholes or use_layer_norm or learn_init:
+        raise NotImplementedError('asr_amd: ScalingHyperLSTMLayer with peepholes / layer norm / learn_init '
+                                  'is not implemented')
+    from .engine_scaling import ScalingPair
+    net = Network(device or 'cuda:0')
+    D = num_inputs
+    inner = []
+    for H, N in zip(num_inner_units_list, num_outer_units_list):
+        pair = ScalingPair(net, len(net.pairs), D, N, H, grad_clipping or 0, 2)
+        net.add_pair(pair, [specs.scaling_hyper_params(D, H, N)] * 2)
+        inner += [InnerHidHandle(pair, d) for d in range(2)]
+        D = pair.out_dim
+    net.set_output(D, num_outputs, 'softmax' if use_softmax else 'logits')
+    net.finalize(seed)
+    return inner + [net] if get_inner_hid else net
+
+
+class InnerHidHandle(object):
+    def __init__(self, pair, d):
+        self.pair = pair; self.d = d
+
+    def get_output(self):
+        return self.pair.inner_hid(self.d)

@@ -174,6 +174,8 @@ typedef struct asr_hyper_dir {
 typedef struct asr_hyper_scan_desc {
     int T, B, N, H, ndir;
     float grad_clip;
+    int clip_outcell;         /* 1: also grad_clip the outcell of both cells (ScalingHyperLSTMLayer,
+                               * libs/lasagne_libs/hyper_layers.py:1023-1025,1083-1085) */
     const float* mask; int mask_stride_b, mask_stride_t;
     asr_hyper_dir dir[2];
 } asr_hyper_scan_desc;

@@ -295,6 +295,109 @@ def hyper_scan_bwd(dhid, x, fwd_cache, p, spec):
 
 
 # --------------------------------------------------------------------------------------------
+# ScalingHyperLSTMLayer scan (libs/lasagne_libs/hyper_layers.py:850-1205) with use_peepholes=False and
+# use_layer_norm=False, the configuration models/gating_hyper_nets.py:27-38 defaults to: the cell-to
+# -gate vectors and the scale_outer_cell map are then non-trainable zeros (:585-588, :716-723) and
+# drop out.  An "inner" LSTM (sees x_t, its own h and the outer h) emits three affine maps of its
+# new hidden state that scale the outer LSTM's input term, recurrent term and bias (:1030-1040).
+# grad_clip is applied per gate pre-activation AND on outcell, for both cells (:992-1022,:1057-1089).
+# p keys: Wi_x (D,4H), Wi_h (H,4H), Wi_o (N,4H), bi (4H); Wo_x (D,4N), Wo_h (N,4N);
+#         S_in, S_hid, S_bias (H,4N) with biases s_in, s_hid, s_bias (4N)
+# --------------------------------------------------------------------------------------------
+def scaling_scan_fwd(x, mask, p, spec):
+    T, B, D = x.shape
+    N, H = spec['N'], spec['H']
+    dt = x.dtype
+    inner_in = x @ p['Wi_x'] + p['bi']                    # :951
+    outer_in = x @ p['Wo_x']                              # :952
+    ic = np.zeros((B, H), dt); ih = np.zeros((B, H), dt)
+    oc = np.zeros((B, N), dt); oh = np.zeros((B, N), dt)
+    order = range(T - 1, -1, -1) if spec.get('backwards') else range(T)
+    hid_i = np.zeros((T, B, H), dt); hid_o = np.zeros((T, B, N), dt)
+    cache = [None] * T
+    for t in order:
+        m = mask[t][:, None] != 0
+        ig = inner_in[t] + ih @ p['Wi_h'] + oh @ p['Wi_o']            # :973-975
+        ii = _sig(ig[:, 0:H]); if_ = _sig(ig[:, H:2 * H]); igc = np.tanh(ig[:, 2 * H:3 * H])
+        ic_new = if_ * ic + ii * igc                                  # :1005
+        io = _sig(ig[:, 3 * H:4 * H])
+        itc = np.tanh(ic_new)
+        ih_new = io * itc                                             # :1025
+        s_in = ih_new @ p['S_in'] + p['s_in']                         # :1030
+        s_hid = ih_new @ p['S_hid'] + p['s_hid']                      # :1031
+        s_b = ih_new @ p['S_bias'] + p['s_bias']                      # :1033
+        a = oh @ p['Wo_h']
+        og = s_in * outer_in[t] + s_hid * a + s_b                     # :1038-1040
+        oi = _sig(og[:, 0:N]); of = _sig(og[:, N:2 * N]); ogc = np.tanh(og[:, 2 * N:3 * N])
+        oc_new = of * oc + oi * ogc                                   # :1071
+        oo = _sig(og[:, 3 * N:4 * N])
+        otc = np.tanh(oc_new)
+        oh_new = oo * otc                                             # :1091
+        cache[t] = (m, ic, ih, oc, oh, ii, if_, igc, io, itc, ih_new, s_in, s_hid, a, oi, of, ogc, oo, otc)
+        ic = np.where(m, ic_new, ic); ih = np.where(m, ih_new, ih)    # step_masked :1097-1118
+        oc = np.where(m, oc_new, oc); oh = np.where(m, oh_new, oh)
+        hid_i[t] = ih; hid_o[t] = oh
+    return hid_i, hid_o, (cache, inner_in, outer_in)
+
+
+def scaling_scan_bwd(dhid_i, dhid_o, x, fwd_cache, p, spec):
+    cache, inner_in, outer_in = fwd_cache
+    T, B, D = x.shape
+    N, H = spec['N'], spec['H']
+    clipv = spec.get('grad_clip', 0)
+    dt = dhid_o.dtype
+    order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
+    g_ = {k: np.zeros_like(v) for k, v in p.items()}
+    doh = np.zeros((B, N), dt); doc = np.zeros((B, N), dt)
+    dih = np.zeros((B, H), dt); dic = np.zeros((B, H), dt)
+    d_inner_in = np.zeros((T, B, 4 * H), dt); d_outer_in = np.zeros((T, B, 4 * N), dt)
+    for t in reversed(order):
+        (m, ic_prev, ih_prev, oc_prev, oh_prev, ii, if_, igc, io, itc, ih_new, s_in, s_hid, a,
+         oi, of, ogc, oo, otc) = cache[t]
+        doh_t = dhid_o[t] + doh
+        dih_t = dhid_i[t] + dih
+        doh_new = np.where(m, doh_t, 0); doh_prev = np.where(m, 0, doh_t)
+        doc_new = np.where(m, doc, 0); doc_prev = np.where(m, 0, doc)
+        dih_new = np.where(m, dih_t, 0); dih_prev = np.where(m, 0, dih_t)
+        dic_new = np.where(m, dic, 0); dic_prev = np.where(m, 0, dic)
+        # outer cell
+        doo = doh_new * otc
+        doc_new = doc_new + _clip(doh_new * oo * (1 - otc * otc), clipv)      # clip on outer_outcell
+        dog = np.concatenate([doc_new * ogc * oi * (1 - oi), doc_new * oc_prev * of * (1 - of),
+                              doc_new * oi * (1 - ogc * ogc), doo * oo * (1 - oo)], axis=1)
+        dog = _clip(dog, clipv)
+        doc_prev = doc_prev + doc_new * of
+        ds_in = dog * outer_in[t]; d_outer_in[t] = dog * s_in
+        ds_hid = dog * a; da = dog * s_hid
+        ds_b = dog
+        g_['Wo_h'] += oh_prev.T @ da
+        doh_prev = doh_prev + da @ p['Wo_h'].T
+        for nm, dsv in (('in', ds_in), ('hid', ds_hid), ('bias', ds_b)):
+            g_['S_' + nm] += ih_new.T @ dsv
+            g_['s_' + nm] += dsv.sum(0)
+            dih_new = dih_new + dsv @ p['S_' + nm].T
+        # inner cell
+        dio = dih_new * itc
+        dic_new = dic_new + _clip(dih_new * io * (1 - itc * itc), clipv)      # clip on inner_outcell
+        dig = np.concatenate([dic_new * igc * ii * (1 - ii), dic_new * ic_prev * if_ * (1 - if_),
+                              dic_new * ii * (1 - igc * igc), dio * io * (1 - io)], axis=1)
+        dig = _clip(dig, clipv)
+        dic_prev = dic_prev + dic_new * if_
+        d_inner_in[t] = dig
+        g_['Wi_h'] += ih_prev.T @ dig
+        g_['Wi_o'] += oh_prev.T @ dig
+        dih_prev = dih_prev + dig @ p['Wi_h'].T
+        doh_prev = doh_prev + dig @ p['Wi_o'].T
+        doh, doc, dih, dic = doh_prev, doc_prev, dih_prev, dic_prev
+    xf = x.reshape(T * B, D)
+    g_['Wi_x'] += xf.T @ d_inner_in.reshape(T * B, -1)
+    g_['bi'] += d_inner_in.sum((0, 1))
+    g_['Wo_x'] += xf.T @ d_outer_in.reshape(T * B, -1)
+    dx = d_inner_in @ p['Wi_x'].T + d_outer_in @ p['Wo_x'].T
+    return dx, g_
+
+
+# --------------------------------------------------------------------------------------------
 # Layer wrappers.  Each takes x (B,T,D) batch-major like the reference layers, a parameter dict
 # keyed by the reference's add_param names, and returns (B,T,out) plus a cache for backward.
 # --------------------------------------------------------------------------------------------
@@ -656,6 +759,47 @@ class HyperLSTMLayerO(OracleLayer):
         return _tm(dx)
 
 
+class ScalingHyperLSTMLayerO(OracleLayer):
+    """libs/lasagne_libs/hyper_layers.py:525-1205 (use_peepholes=False, use_layer_norm=False).  forward
+    returns the OUTER hidden sequence (what models/gating_hyper_nets.py:66-98 feeds upward); the inner
+    hidden sequence is kept in self.inner_hid."""
+    GI = ('W_inner_in_to_inner_{}', 'W_inner_hid_to_inner_{}', 'W_outer_hid_to_inner_{}', 'b_inner_{}')
+
+    def __init__(self, P, num_inner_units, num_outer_units, grad_clipping=0, backwards=False):
+        self.P = P
+        self.spec = dict(N=num_outer_units, H=num_inner_units, grad_clip=grad_clipping, backwards=backwards)
+
+    def forward(self, x, mask, cond=None):
+        P = self.P; G = GATES_REC
+        self.p = dict(Wi_x=_stack(P, 'W_inner_in_to_inner_{}', G), Wi_h=_stack(P, 'W_inner_hid_to_inner_{}', G),
+                      Wi_o=_stack(P, 'W_outer_hid_to_inner_{}', G), bi=_stack(P, 'b_inner_{}', G, 0),
+                      Wo_x=_stack(P, 'W_outer_in_to_outer_{}', G), Wo_h=_stack(P, 'W_outer_hid_to_outer_{}', G),
+                      S_in=_stack(P, 'W_inner_hid_to_outer_in_{}', G), s_in=_stack(P, 'b_inner_hid_to_outer_in_{}', G, 0),
+                      S_hid=_stack(P, 'W_inner_hid_to_outer_hid_{}', G), s_hid=_stack(P, 'b_inner_hid_to_outer_hid_{}', G, 0),
+                      S_bias=_stack(P, 'W_inner_hid_to_outer_bias_{}', G),
+                      s_bias=_stack(P, 'b_inner_hid_to_outer_bias_{}', G, 0))
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        hid_i, hid_o, self.cache = scaling_scan_fwd(self.x, m, self.p, self.spec)
+        self.inner_hid = _tm(hid_i)
+        return _tm(hid_o)
+
+    def backward(self, dy, d_inner=None):
+        dyo = _tm(dy)
+        dyi = np.zeros(dyo.shape[:2] + (self.spec['H'],), dyo.dtype) if d_inner is None else _tm(d_inner)
+        dx, g = scaling_scan_bwd(dyi, dyo, self.x, self.cache, self.p, self.spec)
+        G = {}; G4 = GATES_REC
+        for key, fmt in (('Wi_x', 'W_inner_in_to_inner_{}'), ('Wi_h', 'W_inner_hid_to_inner_{}'),
+                         ('Wi_o', 'W_outer_hid_to_inner_{}'), ('Wo_x', 'W_outer_in_to_outer_{}'),
+                         ('Wo_h', 'W_outer_hid_to_outer_{}'), ('S_in', 'W_inner_hid_to_outer_in_{}'),
+                         ('S_hid', 'W_inner_hid_to_outer_hid_{}'), ('S_bias', 'W_inner_hid_to_outer_bias_{}')):
+            _unstack_into(G, fmt, G4, g[key])
+        for key, fmt in (('bi', 'b_inner_{}'), ('s_in', 'b_inner_hid_to_outer_in_{}'),
+                         ('s_hid', 'b_inner_hid_to_outer_hid_{}'), ('s_bias', 'b_inner_hid_to_outer_bias_{}')):
+            _unstack_into(G, fmt, G4, g[key], axis=0)
+        self.grads = G
+        return _tm(dx)
+
+
 # --------------------------------------------------------------------------------------------
 # Output layer + loss
 # --------------------------------------------------------------------------------------------
@@ -709,7 +853,7 @@ def gen_win(batch, win_size, right_context=0):
 # --------------------------------------------------------------------------------------------
 _KINDS = dict(lstm=LSTMLayerO, lhuc=LHUCLSTMLayerO, prj=ProjectLSTMLayerO,
               ln_prj=LayerNormProjectLSTMLayerO, icond_ln_prj=InputCondLayerNormProjectLSTMLayerO,
-              hyper=HyperLSTMLayerO, rec=RecLayerO)
+              hyper=HyperLSTMLayerO, rec=RecLayerO, scaling=ScalingHyperLSTMLayerO)
 
 
 class OracleNetwork(object):

@@ -319,3 +319,43 @@ def seqsum_lhuc_net(ss, layers, x, mask, N, npl, clip=0):
         sf = pred @ P['W_e_h_%d' % npl] + P['b_e_h_%d' % npl]
         out = hid * torch.relu(sf).unsqueeze(1)
     return out
+
+
+def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False):
+    """libs/lasagne_libs/hyper_layers.py:850-1205 with use_peepholes=False, use_layer_norm=False
+    (peephole vectors and scale_outer_cell are zero constants and are left out).  Returns outer hid."""
+    c = lambda fmt, dim=1: _cat(P, fmt, G_R, dim)
+    W_ii = c('W_inner_in_to_inner_{}'); W_hi = c('W_inner_hid_to_inner_{}'); W_oi = c('W_outer_hid_to_inner_{}')
+    b_i = c('b_inner_{}', 0)
+    W_in = c('W_inner_hid_to_outer_in_{}'); b_in = c('b_inner_hid_to_outer_in_{}', 0)
+    W_hd = c('W_inner_hid_to_outer_hid_{}'); b_hd = c('b_inner_hid_to_outer_hid_{}', 0)
+    W_bs = c('W_inner_hid_to_outer_bias_{}'); b_bs = c('b_inner_hid_to_outer_bias_{}', 0)
+    W_oo_in = c('W_outer_in_to_outer_{}'); W_oo = c('W_outer_hid_to_outer_{}')
+    inp = x.transpose(0, 1)
+    m = mask.transpose(0, 1).unsqueeze(-1)
+    B = inp.shape[1]
+    inner_input = inp @ W_ii + b_i
+    outer_input = inp @ W_oo_in
+
+    def step(inner_input_n, outer_input_n, mask_n, ic_prev, ih_prev, oc_prev, oh_prev):
+        ig = inner_input_n + ih_prev @ W_hi + oh_prev @ W_oi
+        i_in = grad_clip(ig[:, 0:H], clip); i_f = grad_clip(ig[:, H:2 * H], clip); i_c = grad_clip(ig[:, 2 * H:3 * H], clip)
+        inner_cell = torch.sigmoid(i_f) * ic_prev + torch.sigmoid(i_in) * torch.tanh(i_c)
+        i_o = grad_clip(ig[:, 3 * H:4 * H], clip)
+        inner_outcell = grad_clip(inner_cell, clip)
+        inner_hid = torch.sigmoid(i_o) * torch.tanh(inner_outcell)
+        s_in = inner_hid @ W_in + b_in; s_hid = inner_hid @ W_hd + b_hd; s_b = inner_hid @ W_bs + b_bs
+        og = s_in * outer_input_n + s_hid * (oh_prev @ W_oo) + s_b
+        o_in = grad_clip(og[:, 0:N], clip); o_f = grad_clip(og[:, N:2 * N], clip); o_c = grad_clip(og[:, 2 * N:3 * N], clip)
+        outer_cell = torch.sigmoid(o_f) * oc_prev + torch.sigmoid(o_in) * torch.tanh(o_c)
+        o_o = grad_clip(og[:, 3 * N:4 * N], clip)
+        outer_outcell = grad_clip(outer_cell, clip)
+        outer_hid = torch.sigmoid(o_o) * torch.tanh(outer_outcell)
+        k = mask_n != 0
+        return [torch.where(k, inner_cell, ic_prev), torch.where(k, inner_hid, ih_prev),
+                torch.where(k, outer_cell, oc_prev), torch.where(k, outer_hid, oh_prev)]
+
+    z = lambda n: torch.zeros(B, n, dtype=x.dtype)
+    outs = _scan(step, [inner_input, outer_input, m], [z(H), z(H), z(N), z(N)], backwards)
+    hid = outs[3].transpose(0, 1)
+    return hid.flip(1) if backwards else hid

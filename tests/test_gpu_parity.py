@@ -213,6 +213,52 @@ def test_hyperlstm_medium():
     run_case(net, b)
 
 
+@pytest.mark.parametrize('clip', [0.0, 0.05])
+@pytest.mark.parametrize('H', [4, 6])
+def test_scaling_hyper_small(clip, H):
+    """ScalingHyperLSTMLayer stack (hyper_layers.py:525-1205); H=6 exercises the zero padding of the
+    inner width to a multiple of 4."""
+    from asr_amd.gating_hyper_nets import deep_scaling_hyper_model
+    net = deep_scaling_hyper_model(None, None, 5, 6, [H, H], [8, 8], grad_clipping=clip, device=_dev(), seed=21)
+    perturb_params(net, 22, 0.15)
+    b = make_batch(np.random.default_rng(23), 3, 7, 5, 6)
+    run_case(net, b)
+    # padded inner units stay exactly zero in parameters and gradients
+    for pair in net.pairs:
+        for dp in pair.dirs:
+            assert float(dp.p('Whh')[H:].abs().max()) == 0.0 if pair.Hp > H else True
+            assert float(dp.g('M')[H:pair.Hp].abs().max()) == 0.0 if pair.Hp > H else True
+
+
+def test_scaling_hyper_medium_inner_hid():
+    from asr_amd.gating_hyper_nets import deep_scaling_hyper_model
+    out = deep_scaling_hyper_model(None, None, 11, 13, [16, 14], [64, 32], grad_clipping=1.0,
+                                   get_inner_hid=True, use_softmax=False, device=_dev(), seed=24)
+    net = out[-1]; inner = out[:-1]
+    assert len(inner) == 4
+    perturb_params(net, 25, 0.03)
+    b = make_batch(np.random.default_rng(26), 18, 31, 11, 13)
+    run_case(net, b)
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    onet.posteriors(b['x'], b['mask'], None)
+    x = torch.from_numpy(b['x']).to(net.device); m = torch.from_numpy(b['mask']).to(net.device)
+    net.posteriors(x, m, None)
+    for k, h in enumerate(inner):
+        got = h.get_output().cpu().numpy().reshape(31, 18, -1).transpose(1, 0, 2)
+        want = onet.layers[k // 2][k % 2].inner_hid
+        assert relerr(got, want) < 2e-5, k
+
+
+def test_scaling_hyper_reference_widths():
+    """inner 250 / outer 500 (scripts/wsj/exp_scale_hypernet_skip.py): 125 workgroups per direction,
+    inner width padded 250 -> 252."""
+    from asr_amd.gating_hyper_nets import deep_scaling_hyper_model
+    net = deep_scaling_hyper_model(None, None, 123, 50, [250], [500], grad_clipping=1.0, device=_dev(), seed=27)
+    perturb_params(net, 28, 0.01)
+    b = make_batch(np.random.default_rng(29), 4, 24, 123, 50)
+    run_case(net, b, calibrate=True)
+
+
 def test_adam_step_matches_oracle():
     from asr_amd.builders import build_deep_lstm
     net = build_deep_lstm(None, None, 5, 1, 8, 0, 6, 0.0, False, False, 0, device=_dev(), seed=1)

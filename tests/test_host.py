@@ -223,6 +223,10 @@ def test_param_inventories_match_survey_counts():
     # cfg3 per direction L1 2,185,728, L2-4 4,492,288; output 3,521,900; total 34.85 M
     assert count(specs.hyper_params(123, 512, 128, 64)) == 2185728
     assert count(specs.hyper_params(1024, 512, 128, 64)) == 4492288
+    # ScalingHyperLSTMLayer, trainable set at use_peepholes=False / use_layer_norm=False
+    D_, H_, N_ = 123, 250, 500
+    assert count(specs.scaling_hyper_params(D_, H_, N_)) == 4 * (D_ * H_ + H_ * H_ + N_ * H_ + H_) + 4 * (D_ * N_ + N_ * N_ + 3 * (H_ * N_ + N_))
+    assert len(specs.scaling_hyper_params(5, 6, 8)) == 48
     assert count(specs.dense_params(1024, 3436)) == 3521900
     names = [n for n, _, _ in specs.hyper_params(5, 8, 4, 2)]
     assert names[:3] == ['W_hhat_ig', 'W_xhat_ig', 'bhat_ig'] and names[12:17] == [

@@ -107,6 +107,17 @@ def test_hyper_layer(backwards, clip):
            P, b['x'], b['mask'])
 
 
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip', [0, 0.3])
+def test_scaling_hyper_layer(backwards, clip):
+    rng = np.random.default_rng(19)
+    Hs = 6
+    P = make_params(rng, specs.scaling_hyper_params(D, Hs, N), perturb=0.3, scale=1.5)
+    b = make_batch(rng, B, T, D, C)
+    lay = O.ScalingHyperLSTMLayerO(P, Hs, N, clip, backwards)
+    _check(lay, lambda Pt, x, m, c: R.scaling_hyper_layer(Pt, x, m, N, Hs, clip, backwards), P, b['x'], b['mask'])
+
+
 def test_softmax_ce_and_adam():
     rng = np.random.default_rng(15)
     lg = rng.standard_normal((B, T, C)) * 3
