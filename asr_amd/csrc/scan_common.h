@@ -17,9 +17,14 @@
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 
 #define SYNC_SHARDS 16
-#define SYNC_STRIDE ((SYNC_SHARDS + 1) * 32)   // u32 words per group: 16 arrival shards (one 128-B
-                                               // line each) + the abort word on its own line
-#define SYNC_ABORT (SYNC_SHARDS * 32)
+#define SYNC_REPL 8                            // replicas of the sharded counter: a workgroup ADDS to its
+                                               // shard of every replica (one instruction, 8 lanes) and
+                                               // POLLS only replica wg % 8, so a line has G/16 adders and
+                                               // G/8 pollers instead of G pollers (MI355X_MICROARCH.md,
+                                               // polling-cost: 255 pollers of one word = 4 us)
+#define SYNC_STRIDE ((SYNC_REPL * SYNC_SHARDS + 1) * 32)   // u32 words per group, every counter and the
+                                                           // abort word on a 128-B line of its own
+#define SYNC_ABORT (SYNC_REPL * SYNC_SHARDS * 32)
 #define SCAN_DEADLINE_TICKS 1000000000ull      // 10 s of s_memrealtime (100 MHz)
 
 // One arrival counter serialises G atomics at the memory side (~12 ns each: measured 2.1 us of a
@@ -29,6 +34,7 @@ struct GroupSync {
     unsigned G;                 // workgroups in the group
     unsigned epoch;             // exchanges completed so far (uniform across the group)
     unsigned my_shard;          // shard this workgroup arrives on
+    unsigned my_repl;           // replica this workgroup polls
     unsigned members;           // lane s < SYNC_SHARDS: number of workgroups arriving on shard s
     unsigned long long deadline;
     int* lds_flag;              // one LDS int for broadcasting the poll result
@@ -38,6 +44,7 @@ __device__ __forceinline__ void group_sync_init(GroupSync& gs, unsigned* words, 
                                                 int* lds_flag) {
     gs.words = words; gs.G = G; gs.epoch = 0; gs.lds_flag = lds_flag;
     gs.my_shard = wg % SYNC_SHARDS;
+    gs.my_repl = wg % SYNC_REPL;
     const unsigned lane = threadIdx.x & 63;
     gs.members = lane < SYNC_SHARDS ? (G > lane ? (G - lane + SYNC_SHARDS - 1) / SYNC_SHARDS : 0) : 0;
     gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS;
@@ -46,20 +53,35 @@ __device__ __forceinline__ void group_sync_init(GroupSync& gs, unsigned* words, 
 __device__ __forceinline__ void group_publish(GroupSync& gs) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its sc1 stores
     __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(gs.words + gs.my_shard * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < SYNC_REPL)
+        __hip_atomic_fetch_add(gs.words + (threadIdx.x * SYNC_SHARDS + gs.my_shard) * 32, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The same arrival when only ONE wave of the workgroup stored payload for this exchange: that wave
+// drains and arrives by itself, the other waves neither wait nor meet at a barrier (their loads stay
+// in flight).  `storing_wave` is wave-uniform.
+__device__ __forceinline__ void group_publish_wave(GroupSync& gs, bool storing_wave) {
+    if (storing_wave) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) < SYNC_REPL)
+            __hip_atomic_fetch_add(gs.words + ((threadIdx.x & 63) * SYNC_SHARDS + gs.my_shard) * 32, 1u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // returns false when the group aborted (timeout somewhere): caller must leave its loop
 __device__ __forceinline__ bool group_wait(GroupSync& gs) {
     gs.epoch += 1;
-    if (threadIdx.x < 64) {                               // wave 0 polls: lane s watches shard s,
-        const unsigned lane = threadIdx.x;                // lane SYNC_SHARDS watches the abort word
+    if ((threadIdx.x >> 6) == (blockDim.x >> 6) - 1) {    // the LAST wave polls (it owns no per-step global
+        const unsigned lane = threadIdx.x & 63;           // loads that would queue in front of the poll):
+                                                          // lane s watches shard s, lane 16 the abort word
         const unsigned target = gs.epoch * gs.members;
         int good = 1;
         for (;;) {
             unsigned v = 0;
-            if (lane <= SYNC_SHARDS) v = ld_sc1_u32(gs.words + lane * 32);
+            if (lane <= SYNC_SHARDS)
+                v = ld_sc1_u32(lane < SYNC_SHARDS ? gs.words + (gs.my_repl * SYNC_SHARDS + lane) * 32 : gs.words + SYNC_ABORT);
             const bool arrived = lane < SYNC_SHARDS ? v >= target : true;
             const bool aborted = (lane == SYNC_SHARDS) && v != 0;
             if (__any(aborted)) { good = 0; break; }

@@ -36,6 +36,7 @@ struct HyperDir {
 
 struct HyperArgs {
     int T, B, N, H, G, UH, KS, KSP, KT, HS, HSP, HT;
+    int R, MT, KQ, NBLK, NBW;    // backward W_h product: see hyper_dims
     int ndir, chunk0, rpc;       // rpc = batch rows per chunk/group (8 or 16)
     float clip;
     float clip_out;              // bound of the extra grad_clip on outcell (ScalingHyperLSTMLayer), 0 = none
@@ -44,7 +45,8 @@ struct HyperArgs {
     unsigned* sync;
     float* rex;      // [ng][2][KS][64]
     float* hex;      // [ng][2][G][64]
-    float* dex;      // [ng][2][KS dst][G src][64]
+    float* dax;      // [ng][2][G src][64 lanes][4]: da of the source's 16 gate columns (all-gather)
+    float* px;       // [ng][2][G src][4 waves][16 units][16 b]: partial W_h.da tiles (R-way reduce)
     float* dhx;      // [ng][2][G dst][G src][UH*16]
     float* dgx;      // [ng][2][H][16][4]
     unsigned long long* dbg;   // STAMP_BYTES at the workspace tail (diagnostic builds)
@@ -58,12 +60,23 @@ static inline void hyper_dims(int N, int H, HyperArgs* A) {
     int uh = 1;
     while (uh * A->G < H) uh *= 2;
     A->UH = uh;
+    // Backward dh_{t-1} = W_h . da as a 2-D decomposition: R consecutive workgroups form a unit block
+    // (4R units); member kr multiplies the block's rows with ITS 1/R of the gate columns (all-gathered
+    // da of NBLK source workgroups) and the R partial tiles are summed by the unit owners.  R = the
+    // largest divisor of G that is <= 8 (8 = one K range per XCD under round-robin dispatch).
+    int r = 1;
+    for (int c = 2; c <= 8; ++c) if (A->G % c == 0) r = c;
+    A->R = r;
+    A->MT = (4 * r + 15) / 16;              // 16-unit tiles per block (1 or 2)
+    A->KQ = 4 / A->MT;                      // K slices per workgroup = waves per tile
+    A->NBLK = A->G / r;                     // source workgroups (16-column blocks) per K range
+    A->NBW = (A->NBLK + A->KQ - 1) / A->KQ; // blocks per wave
 }
 static inline size_t hyper_pack_floats_wg(const HyperArgs& A, int mode) {
     const int CR = 4 * A.UH;
     const int S4P = ((A.H + 15) / 16) * 16;
     if (mode == 0) return (size_t)A.KSP * 64 + (size_t)(A.KSP + A.HSP) * 4 * CR + (size_t)3 * A.HSP * 64;
-    return (size_t)A.KT * 256 + (size_t)A.HT * 3 * 256 + (size_t)S4P * 4 * (4 + A.UH);
+    return (size_t)A.NBW * 1024 + (size_t)A.HT * 3 * 256 + (size_t)S4P * 4 * (4 + A.UH);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -111,11 +124,17 @@ __global__ void hyper_pack_kernel(const float* __restrict__ Wh, const float* __r
             od[i] = row < H ? M[(size_t)row * 12 * N + (size_t)tau * 4 * N + j * 16 + (l & 15)] : 0.f;
         }
     } else {
-        const size_t n1 = (size_t)A.KT * 256;
+        // W_h rows of the unit block against the own K range, as B operands (k = column, n = unit) of
+        // 16x16x4 MFMAs: [wave][block of the wave][lane][e], wave = kq*MT + mt
+        const size_t n1 = (size_t)A.NBW * 1024;
+        const int ub = j / A.R, kr = j % A.R;
         for (size_t i = threadIdx.x; i < n1; i += blockDim.x) {
-            const int e = i & 3, l = (i >> 2) & 63, kt = (int)(i >> 8);
-            const int row = kt * 16 + (l & 15), col = j * 16 + 4 * e + (l >> 4);
-            o[i] = row < N ? Wh[(size_t)row * 4 * N + col] : 0.f;
+            const int e = i & 3, l = (i >> 2) & 63, ib = (int)((i >> 8) % A.NBW), w = (int)((i >> 8) / A.NBW);
+            const int mt = w % A.MT, kq = w / A.MT;
+            const int bi = kq * A.NBW + ib;                       // block inside the K range
+            const int ul = mt * 16 + (l & 15);                    // unit inside the unit block
+            const int row = ub * 4 * A.R + ul, col = (kr * A.NBLK + bi) * 16 + 4 * e + (l >> 4);
+            o[i] = (bi < A.NBLK && ul < 4 * A.R) ? Wh[(size_t)row * 4 * N + col] : 0.f;
         }
         float* om = o + n1;
         const size_t n2 = (size_t)A.HT * 3 * 256;
@@ -132,7 +151,7 @@ __global__ void hyper_pack_kernel(const float* __restrict__ Wh, const float* __r
         for (size_t i = threadIdx.x; i < n3; i += blockDim.x) {
             const int e = i & 3, ir = (int)((i >> 2) % RR), qq = (int)(((i >> 2) / RR) & 3);
             const int s4 = (int)(((i >> 2) / RR) >> 2);
-            const int col = 4 * (4 * s4 + e) + qq;              // column of the 4H-wide hyper gate vector
+            const int col = 4 * (4 * s4 + qq) + e;              // hyper unit 4*s4+qq (MFMA k), gate e (MFMA step)
             float v = 0.f;
             if (col < 4 * H) {
                 if (ir < 4) v = Whx[(size_t)(j * 4 + ir) * 4 * H + col];
@@ -405,18 +424,19 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+#define DAB 8      // da blocks per wave put in flight early (covers NBW <= 8, e.g. G = 128 with R = 8)
 __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t per_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int N = A.N, H = A.H, UH = A.UH, KS = A.KS, KT = A.KT, HT = A.HT;
+    const int N = A.N, H = A.H, UH = A.UH, HT = A.HT;
     const int T = A.T, B = A.B, G = A.G;
     const int S4P = ((H + 15) / 16) * 16;
     const int UHB = UH * 16;
-    float* Wb = smem;                                   // [KT][64][4]
-    float* Mb = Wb + (size_t)KT * 256;                  // [HT][3][64][4]
+    float* Wt = smem;                                   // [4 waves][NBW][64][4]
+    float* Mb = Wt + (size_t)A.NBW * 1024;              // [HT][3][64][4]
     float* Rw = Mb + (size_t)HT * 3 * 256;              // [S4P/4][4][4+UH][4]
     float* dal = Rw + (size_t)S4P * 4 * (4 + UH);                 // [16 cols][16 b]            da
     float* dDl = dal + 256;                             // [3][16 cols][16 b]         dD
-    float* rsum = dDl + 768;                            // [16 sg][16][4]             dex gather
+    float* rsum = dDl + 768;                            // [16 pieces][4 units][16 b] W_h . da partial gather
     float* hsum = rsum + 1024;                          // [256]                      dhx gather partials
     float* red = hsum + 256;                            // [4 waves][64][4]           Rw product
     int* flag = (int*)(red + 1024);
@@ -436,18 +456,27 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         f32x4* dst = (f32x4*)smem;
         for (size_t i = tid; i < per_wg / 4; i += 256) dst[i] = src[i];
     }
-    float* dex = A.dex + (size_t)grp * 2 * KS * G * 64;
+    float* dax = A.dax + (size_t)grp * 2 * G * 256;
+    float* px = A.px + (size_t)grp * 2 * G * 1024;
     float* dhx = A.dhx + (size_t)grp * 2 * G * G * UHB;
     float* dgx = A.dgx + (size_t)grp * 2 * H * 64;
-    const __amdgpu_buffer_rsrc_t dex_rs = make_rsrc_(dex, (unsigned)((size_t)2 * KS * G * 64 * 4));
+    const __amdgpu_buffer_rsrc_t dax_rs = make_rsrc_(dax, (unsigned)((size_t)2 * G * 256 * 4));
+    const __amdgpu_buffer_rsrc_t px_rs = make_rsrc_(px, (unsigned)((size_t)2 * G * 1024 * 4));
     const __amdgpu_buffer_rsrc_t dgx_rs = make_rsrc_(dgx, (unsigned)((size_t)2 * H * 64 * 4));
     const __amdgpu_buffer_rsrc_t dhx_rs = make_rsrc_(dhx, (unsigned)((size_t)2 * G * G * UHB * 4));
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // W_h product roles: this wave's tile / K slice, first source block of its slice
+    const int R = A.R, MT = A.MT, KQ = A.KQ, NBW = A.NBW;
+    const int ub = j / R, kr = j % R;
+    const int w_mt = wv % MT, w_kq = wv / MT;
+    const int w_bi0 = w_kq * NBW;                        // first block of this wave inside the K range
+    const int w_blk0 = kr * A.NBLK + w_bi0;              // ... as a source workgroup index
+    const float* Ww = Wt + (size_t)wv * NBW * 256;
 
     const int unit = j * 4 + q, col4 = unit * 4;
     const int hu = j * UH + q;
     const bool hvalid = (q < UH) && (hu < H);
-    float dc = 0.f, dh_pass = 0.f, dh_hyp = 0.f;        // wave 0 lanes
+    float dc = 0.f, dh_pass = 0.f, dh_in = 0.f;         // wave 0 lanes
     float dhc = 0.f, dhh_pass = 0.f, dhh_rec = 0.f;     // wave 1 lanes
     __syncthreads();
 
@@ -466,24 +495,34 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     const int huq = hvalid ? hu : 0;
     const bool w0 = (wv == 0), w1 = (wv == 1);
     const float* const dummy = D.wpack;
+    // address = wave-uniform base of the time step (scalar arithmetic) + loop-invariant 32-bit lane
+    // offset: the whole prefetch is ~a dozen scalar multiplies and saddr loads, no vector 64-bit math
+    const unsigned lo_m = (w0 || w1) ? (unsigned)(bq * A.msb) : 0u;
+    const unsigned lo_g = w0 ? (unsigned)(bq * 4 * N + col4) : 0u;
+    const unsigned lo_a0 = w0 ? (unsigned)(bq * 12 * N + col4) : 0u;
+    const unsigned lo_a1 = w0 ? lo_a0 + 4u * N : 0u, lo_a2 = w0 ? lo_a0 + 8u * N : 0u;
+    const unsigned lo_c = w0 ? (unsigned)(bq * N + unit) : 0u;
+    const unsigned lo_dr = w0 ? (unsigned)(bq * D.ld_dr + unit) : 0u;
+    const unsigned lo_hg = w1 ? (unsigned)(bq * 4 * H + huq * 4) : 0u;
+    const unsigned lo_hc = w1 ? (unsigned)(bq * H + huq) : 0u;
     auto prefetch = [&](int step) {
         const int st = T - 1 - step;
         const int t = D.reverse ? T - 1 - st : st;
         const int tprev = st > 0 ? (D.reverse ? t + 1 : t - 1) : t;
-        const size_t row = (size_t)t * B + bq, rowp = (size_t)tprev * B + bq;
-        const float* ad_ = D.aD + row * 12 * N;
-        n_m = *((w0 || w1) ? A.mask + ((size_t)bq * A.msb + (size_t)t * A.mst) : dummy);
-        n_g4 = *(const f32x4*)(w0 ? D.gates + row * 4 * N + col4 : dummy);
-        n_a4 = *(const f32x4*)(w0 ? ad_ + col4 : dummy);
-        n_dh4 = *(const f32x4*)(w0 ? ad_ + 4 * N + col4 : dummy);
-        n_dx4 = *(const f32x4*)(w0 ? ad_ + 8 * N + col4 : dummy);
-        n_x4 = *(const f32x4*)(w0 ? D.xproj + row * 4 * N + col4 : dummy);
-        n_cnew = *(w0 ? D.cst + row * N + unit : dummy);
-        n_cprev = *(w0 ? D.cst + rowp * N + unit : dummy);
-        n_dre = *(w0 ? D.dr_ext + row * D.ld_dr + unit : dummy);
-        n_hg4 = *(const f32x4*)(w1 ? D.hgates + row * 4 * H + huq * 4 : dummy);
-        n_hcnew = *(w1 ? D.hcst + row * H + huq : dummy);
-        n_hcprev = *(w1 ? D.hcst + rowp * H + huq : dummy);
+        const size_t r0 = (size_t)t * B, rp = (size_t)tprev * B;           // wave-uniform
+        n_m = ((w0 || w1) ? A.mask + (size_t)t * A.mst : dummy)[lo_m];
+        n_g4 = *(const f32x4*)((w0 ? D.gates + r0 * 4 * N : dummy) + lo_g);
+        const float* pa = w0 ? D.aD + r0 * 12 * N : dummy;
+        n_a4 = *(const f32x4*)(pa + lo_a0);
+        n_dh4 = *(const f32x4*)(pa + lo_a1);
+        n_dx4 = *(const f32x4*)(pa + lo_a2);
+        n_x4 = *(const f32x4*)((w0 ? D.xproj + r0 * 4 * N : dummy) + lo_g);
+        n_cnew = (w0 ? D.cst + r0 * N : dummy)[lo_c];
+        n_cprev = (w0 ? D.cst + rp * N : dummy)[lo_c];
+        n_dre = (w0 ? D.dr_ext + r0 * D.ld_dr : dummy)[lo_dr];
+        n_hg4 = *(const f32x4*)((w1 ? D.hgates + r0 * 4 * H : dummy) + lo_hg);
+        n_hcnew = (w1 ? D.hcst + r0 * H : dummy)[lo_hc];
+        n_hcprev = (w1 ? D.hcst + rp * H : dummy)[lo_hc];
     };
     prefetch(0);
     STAMP_DECL
@@ -497,19 +536,12 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         const f32x4 g4 = n_g4, a4 = n_a4, dh4 = n_dh4, dx4 = n_dx4, x4 = n_x4, hg4 = n_hg4;
         const float c_new = n_cnew, c_prev = st > 0 ? n_cprev : 0.f, dre = bvalid ? n_dre : 0.f;
         const float hc_new = n_hcnew, hc_prev = st > 0 ? n_hcprev : 0.f;
-        prefetch(step + 1 < T ? step + 1 : step);
         STAMP(9);
 
         // ---- S1: main cell backward (wave 0)
         f32x4 dg4 = {0, 0, 0, 0}, da4 = {0, 0, 0, 0}, dd_h = {0, 0, 0, 0}, dd_x = {0, 0, 0, 0};
         if (wave == 0) {
-            // dh_sum: contributions published at the end of the previous backward step
-            float dh_sum = 0.f;
-            if (step > 0) {
-#pragma unroll
-                for (int sgi = 0; sgi < 16; ++sgi) dh_sum += rsum[((size_t)sgi * 16 + bl) * 4 + q];
-            }
-            const float dh_t = dre + dh_pass + dh_sum + dh_hyp;
+            const float dh_t = dre + dh_pass + dh_in;       // dh_in: recurrent terms formed last step
             if (on) {
                 const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
                 const float tc = tanhf_(c_new);
@@ -534,39 +566,41 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                 dDl[1 * 256 + (q * 4 + k) * 16 + bl] = dd_x[k];
                 dDl[2 * 256 + (q * 4 + k) * 16 + bl] = dg4[k];
             }
+            // all-gather payload: da of the own 16 columns in the operand order of the consumers'
+            // 4x4x1 MFMAs (lane = ks*16 + b holds columns 4e+ks, e = 0..3): a 4x4 transpose through the
+            // LDS tile just written (one wave, LDS executes a wave's accesses in order), then ONE
+            // 16-byte write-through store per lane = 1 KB per workgroup and step
+            if (step + 1 < T) {
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                f32x4 dap;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dap[e] = dal[((e * 4 + q) * 16) + bl];
+                st_sc1_f4(dax_rs, (unsigned)((((size_t)par * G + j) * 256 + lane * 4) * 4), dap);
+            }
         }
         STAMP(0);
         __syncthreads();
-        // ---- S2: partial dh_{prev} (-> dex) and partial dhhat_t (-> dhx)
-        if (step + 1 < T) {
-            for (int kt = wave; kt < KT; kt += 4) {
-                f32x4 acc = {0, 0, 0, 0};
-                const f32x4 av = *(const f32x4*)(Wb + ((size_t)kt * 64 + lane) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = mfma4(av[e], dal[(4 * e + q) * 16 + bl], acc);
-                const int dst = kt * 4 + q;
-                if (dst < KS)
-                    st_sc1_f4(dex_rs, (unsigned)(((((size_t)par * KS + dst) * G + j) * 64 + bl * 4) * 4), acc);
-            }
-        }
+        // ---- S2: partial dhhat_t over the own 48 columns of M (-> dhx, reduce-scatter).  dD^T is the A
+        // operand (rows = batch) and M^T the B operand (columns = hyper units), so a lane's accumulator
+        // holds 4 consecutive batch rows of one hyper unit: one 16-byte write-through store per tile
         for (int ht = wave; ht < HT; ht += 4) {
             f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int tau = 0; tau < 3; ++tau) {
                 const f32x4 mv = *(const f32x4*)(Mb + (((size_t)ht * 3 + tau) * 64 + lane) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = mfma4(mv[e], dDl[tau * 256 + (4 * e + q) * 16 + bl], acc);
+                for (int e = 0; e < 4; ++e) acc = mfma4(dDl[tau * 256 + (4 * e + q) * 16 + bl], mv[e], acc);
             }
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int hq = ht * 16 + q * 4 + rg;              // hyper unit of this accumulator reg
-                if (hq < H)
-                    st_sc1(dhx + (((size_t)par * G + hq / UH) * G + j) * UHB + (hq % UH) * 16 + bl, acc[rg]);
-            }
+            const int hq = ht * 16 + bl;                      // hyper unit of this lane's accumulator
+            if (hq < H)
+                st_sc1_f4(dhx_rs, (unsigned)(((((size_t)par * G + hq / UH) * G + j) * UHB + (hq % UH) * 16 + q * 4) * 4), acc);
         }
         STAMP(1);
         group_publish(gs);
         STAMP(2);
+        // next step's saved tensors: issued here, in the shadow of exchange 1 (the poll runs on the last
+        // wave, so these loads do not queue in front of its poll results)
+        prefetch(step + 1 < T ? step + 1 : step);
         if (wave == 0 && bvalid) {        // bulk outputs after the publish: off the critical path
             *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
             *(f32x4*)(D.dXp + row * 4 * N + col4) = dg4 * dx4;
@@ -577,7 +611,11 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         }
         if (!group_wait(gs)) break;
         STAMP(3);
-        // ---- S3: gather dhx for own hyper units; gather dex for own main units (used next step)
+        // ---- S3: gather dhx for own hyper units.  Behind its loads, the first DAB blocks per wave of
+        // the all-gathered da are put in flight already (consumed after publish2): their latency
+        // overlaps S3, the hyper cell and the second exchange
+        f32x4 dav[DAB];
+        const unsigned da_sbase = (unsigned)(((size_t)par * G + w_blk0) * 1024);
         {
             const int e = tid % UHB, s0 = tid / UHB, sstep = 256 / UHB;
             float acc = 0.f;
@@ -594,25 +632,10 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc += v[i];
             }
+#pragma unroll
+            for (int i = 0; i < DAB; ++i)
+                dav[i] = ldb_sc1_f4(dax_rs, (unsigned)(lane * 16), da_sbase + (unsigned)(i * 1024));
             hsum[tid] = acc;
-        }
-        if (step + 1 < T) {
-            const int sg = tid >> 4, f4 = tid & 15;
-            f32x4 acc = {0, 0, 0, 0};
-            const unsigned sbase = (unsigned)((((size_t)par * KS + j) * G) * 256);
-            const unsigned voff = (unsigned)((sg * 64 + f4 * 4) * 4);
-            for (int c0 = 0; c0 < G; c0 += 8 * 16) {
-                f32x4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    v[i] = ldb_sc1_f4(dex_rs, voff, sbase + (unsigned)((c0 + i * 16) * 256));
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (sg + c0 + i * 16 >= G) v[i] = f32x4{0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc += v[i];
-            }
-            *(f32x4*)(rsum + ((size_t)sg * 16 + f4) * 4) = acc;
         }
         STAMP(4);
         __syncthreads();
@@ -646,30 +669,72 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             if (wave == 1 && hvalid && bvalid) *(f32x4*)(D.dXh + row * 4 * H + hu * 4) = dhg;
             break;
         }
+        // ---- partial dh_{t-1}: rows of the unit block x own K range of the all-gathered da (published
+        // with exchange 1).  da^T is the A operand (rows = batch), W_h^T the B operand (columns = units):
+        // a lane's accumulator = 4 consecutive batch rows of one unit -> one 16-byte store per lane
+        {
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < DAB; ++i) {
+                const bool ok = (i < NBW) && (w_bi0 + i < A.NBLK);
+                const f32x4 wt = *(const f32x4*)(Ww + ((size_t)(i < NBW ? i : 0) * 64 + lane) * 4);
+                const f32x4 dv = ok ? dav[i] : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma4(dv[e], wt[e], acc);
+            }
+            for (int i0 = DAB; i0 < NBW; i0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = ldb_sc1_f4(dax_rs, (unsigned)(lane * 16), da_sbase + (unsigned)((i0 + i) * 1024));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = (i0 + i < NBW) && (w_bi0 + i0 + i < A.NBLK);
+                    const f32x4 wt = *(const f32x4*)(Ww + ((size_t)(i0 + i < NBW ? i0 + i : 0) * 64 + lane) * 4);
+                    const f32x4 dv = ok ? v[i] : f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma4(dv[e], wt[e], acc);
+                }
+            }
+            // tile [unit bl][batch q*4..q*4+3] of this wave
+            st_sc1_f4(px_rs, (unsigned)(((((size_t)par * G + j) * 4 + wv) * 256 + bl * 16 + q * 4) * 4), acc);
+        }
         group_publish(gs);
         STAMP(6);
         if (wave == 1 && hvalid && bvalid) *(f32x4*)(D.dXh + row * 4 * H + hu * 4) = dhg;
+        STAMP(11);
         if (!group_wait(gs)) break;
         STAMP(7);
-        // ---- S5: own rows of [W_xhat[:N] ; W_hhat] times the gathered hyper gate grads
+        // ---- S5: own rows of [W_xhat[:N] ; W_hhat] times the gathered hyper gate grads; gather of the
+        // R x KQ partial W_h.da pieces (4 own units x 16 batch = 256 B each) of the own unit block
+        {
+            const int pc = tid >> 4, f4 = tid & 15;           // piece = (member s, K slice kq2)
+            const int s_ = pc / KQ, kq2 = pc % KQ;
+            const int ul = kr * 4;                            // own units inside the block
+            const int tile = kq2 * MT + ul / 16;
+            f32x4 v = ldb_sc1_f4(px_rs, (unsigned)((((ul & 15) * 16) + f4 * 4) * 4),
+                                 (unsigned)(((((size_t)par * G + ub * R + (s_ < R ? s_ : 0)) * 4 + tile) * 256) * 4));
+            if (s_ >= R) v = f32x4{0, 0, 0, 0};
+            *(f32x4*)(rsum + ((size_t)pc * 16 + f4) * 4) = v;
+        }
         {
             f32x4 acc = {0, 0, 0, 0};
             const int RR = 4 + UH;
             const int ir = (bl < RR ? bl : RR - 1);
             const int n4 = S4P / 16;
             for (int c0 = 0; c0 < n4; c0 += 8) {
-                float bv[32];
+                f32x4 bv[8];
 #pragma unroll
-                for (int i = 0; i < 32; ++i)     // k-step s = hyper unit, k = gate q: dgx[par][s][bl][q]
-                    bv[i] = ldb_sc1(dgx_rs, (unsigned)((bl * 4 + q) * 4),
-                                    (unsigned)(par * H * 256) + (unsigned)((wv * n4 + c0) * 4 + i) * 256u);
+                for (int i = 0; i < 8; ++i)      // MFMA k = hyper unit 4*s4+q, step e = gate: dgx[par][unit][bl][0..3]
+                    bv[i] = ldb_sc1_f4(dgx_rs, (unsigned)((q * 64 + bl * 4) * 4),
+                                       (unsigned)(par * H * 256) + (unsigned)(wv * n4 + c0 + i) * 1024u);
 #pragma unroll
                 for (int g4i = 0; g4i < 8; ++g4i) {
                     if (c0 + g4i < n4) {
                         const int s4 = wave * n4 + c0 + g4i;
                         const f32x4 rv = *(const f32x4*)(Rw + (((size_t)s4 * 4 + q) * RR + ir) * 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc = mfma4(rv[e], bv[g4i * 4 + e], acc);
+                        for (int e = 0; e < 4; ++e) acc = mfma4(rv[e], bv[g4i][e], acc);
                     }
                 }
             }
@@ -681,7 +746,9 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += red[((size_t)w * 64 + (0 * 16 + bl)) * 4 + q];
-            dh_hyp = v;
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) v += rsum[pc * 64 + q * 16 + bl];        // R x KQ partial pieces
+            dh_in = v;
         }
         if (wave == 1) {
             float v = 0.f;
@@ -714,7 +781,8 @@ extern "C" size_t asr_hyper_scan_ws_bytes(int T, int B, int N, int H, int ndir, 
     size_t bytes = ng * SYNC_STRIDE * 4;
     bytes += ng * 2 * A.KS * 64 * 4 + ng * 2 * A.G * 64 * 4;
     if (backward) {
-        bytes += ng * 2 * (size_t)A.KS * A.G * 64 * 4;
+        bytes += ng * 2 * (size_t)A.G * 256 * 4;
+        bytes += ng * 2 * (size_t)A.G * 1024 * 4;
         bytes += ng * 2 * (size_t)A.G * A.G * A.UH * 16 * 4;
         bytes += ng * 2 * (size_t)H * 64 * 4;
     }
@@ -762,9 +830,10 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     A.sync = (unsigned*)p;  p += ng * SYNC_STRIDE * 4;
     A.rex = (float*)p;      p += ng * 2 * A.KS * 64 * 4;
     A.hex = (float*)p;      p += ng * 2 * A.G * 64 * 4;
-    A.dex = A.dhx = A.dgx = nullptr;
+    A.dax = A.px = A.dhx = A.dgx = nullptr;
     if (backward) {
-        A.dex = (float*)p;  p += ng * 2 * (size_t)A.KS * A.G * 64 * 4;
+        A.dax = (float*)p;  p += ng * 2 * (size_t)A.G * 256 * 4;
+        A.px = (float*)p;   p += ng * 2 * (size_t)A.G * 1024 * 4;
         A.dhx = (float*)p;  p += ng * 2 * (size_t)A.G * A.G * A.UH * 16 * 4;
         A.dgx = (float*)p;
     }
