@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     // saved tensors of the step about to be processed, prefetched one step ahead
     f32x4 n_g4 = {0, 0, 0, 0}, n_a4 = {0, 0, 0, 0}, n_dh4 = {0, 0, 0, 0}, n_dx4 = {0, 0, 0, 0}, n_x4 = {0, 0, 0, 0};
     f32x4 n_hg4 = {0, 0, 0, 0};
-    float n_m = 0.f, n_cnew = 0.f, n_cprev = 0.f, n_dre = 0.f, n_hcnew = 0.f, n_hcprev = 0.f;
+    float n_m = 0.f, n_dre = 0.f;
     // Branch-free on purpose.  Any control-flow join behind these loads (`st > 0 ? load : 0`, a
     // wave-role `if`, `if (step + 1 < T)`) makes hipcc place the phi copies of the loaded registers
     // right behind the loads, i.e. an s_waitcnt vmcnt(0..1) that puts the whole memory latency
@@ -495,36 +495,51 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     const int huq = hvalid ? hu : 0;
     const bool w0 = (wv == 0), w1 = (wv == 1);
     const float* const dummy = D.wpack;
-    // address = wave-uniform base of the time step (scalar arithmetic) + loop-invariant 32-bit lane
-    // offset: the whole prefetch is ~a dozen scalar multiplies and saddr loads, no vector 64-bit math
-    const unsigned lo_m = (w0 || w1) ? (unsigned)(bq * A.msb) : 0u;
-    const unsigned lo_g = w0 ? (unsigned)(bq * 4 * N + col4) : 0u;
-    const unsigned lo_a0 = w0 ? (unsigned)(bq * 12 * N + col4) : 0u;
-    const unsigned lo_a1 = w0 ? lo_a0 + 4u * N : 0u, lo_a2 = w0 ? lo_a0 + 8u * N : 0u;
-    const unsigned lo_c = w0 ? (unsigned)(bq * N + unit) : 0u;
-    const unsigned lo_dr = w0 ? (unsigned)(bq * D.ld_dr + unit) : 0u;
-    const unsigned lo_hg = w1 ? (unsigned)(bq * 4 * H + huq * 4) : 0u;
-    const unsigned lo_hc = w1 ? (unsigned)(bq * H + huq) : 0u;
-    auto prefetch = [&](int step) {
-        const int st = T - 1 - step;
-        const int t = D.reverse ? T - 1 - st : st;
-        const int tprev = st > 0 ? (D.reverse ? t + 1 : t - 1) : t;
-        const size_t r0 = (size_t)t * B, rp = (size_t)tprev * B;           // wave-uniform
-        n_m = ((w0 || w1) ? A.mask + (size_t)t * A.mst : dummy)[lo_m];
-        n_g4 = *(const f32x4*)((w0 ? D.gates + r0 * 4 * N : dummy) + lo_g);
-        const float* pa = w0 ? D.aD + r0 * 12 * N : dummy;
-        n_a4 = *(const f32x4*)(pa + lo_a0);
-        n_dh4 = *(const f32x4*)(pa + lo_a1);
-        n_dx4 = *(const f32x4*)(pa + lo_a2);
-        n_x4 = *(const f32x4*)((w0 ? D.xproj + r0 * 4 * N : dummy) + lo_g);
-        n_cnew = (w0 ? D.cst + r0 * N : dummy)[lo_c];
-        n_cprev = (w0 ? D.cst + rp * N : dummy)[lo_c];
-        n_dre = (w0 ? D.dr_ext + r0 * D.ld_dr : dummy)[lo_dr];
-        n_hg4 = *(const f32x4*)((w1 ? D.hgates + r0 * 4 * H : dummy) + lo_hg);
-        n_hcnew = (w1 ? D.hcst + r0 * H : dummy)[lo_hc];
-        n_hcprev = (w1 ? D.hcst + rp * H : dummy)[lo_hc];
+    // Per-lane pointers that walk the saved tensors one time step per iteration (bumped by a signed
+    // per-lane stride; 0 for the lanes that read the dummy line): the in-loop prefetch is a dozen loads
+    // and pointer adds, with no kernel-argument reloads or 64-bit multiplies on the step's critical path
+    const int dt = D.reverse ? 1 : -1;
+    const size_t r00 = (size_t)(D.reverse ? 0 : T - 1) * B + bq;          // row of the first step
+    const bool w01 = w0 || w1;
+    const float* p_m = w01 ? A.mask + (size_t)(D.reverse ? 0 : T - 1) * A.mst + (size_t)bq * A.msb : dummy;
+    const float* p_g = w0 ? D.gates + r00 * 4 * N + col4 : dummy;
+    const float* p_x = w0 ? D.xproj + r00 * 4 * N + col4 : dummy;
+    const float* p_a = w0 ? D.aD + r00 * 12 * N + col4 : dummy;
+    const float* p_dr = w0 ? D.dr_ext + r00 * D.ld_dr + unit : dummy;
+    const float* p_hg = w1 ? D.hgates + r00 * 4 * H + huq * 4 : dummy;
+    const int s_m = w01 ? dt * A.mst : 0;
+    const int s_g = w0 ? dt * B * 4 * N : 0, s_a = w0 ? dt * B * 12 * N : 0, s_c = w0 ? dt * B * N : 0;
+    const int s_dr = w0 ? dt * B * D.ld_dr : 0;
+    const int s_hg = w1 ? dt * B * 4 * H : 0, s_hc = w1 ? dt * B * H : 0;
+    const int a_1 = w0 ? 4 * N : 0, a_2 = w0 ? 8 * N : 0;
+    // The previous cell state of backward step s is the cell row of step s+1, so the two cell tensors
+    // are read ONCE, two steps ahead (c0 = this step, c1 = next step = this step's c_prev, n_c2 in
+    // flight); a second load of the same row behind a select made hipcc merge the two loads' results at
+    // a join, i.e. wait for the fresh load (see above).
+    auto row_of = [&](int k) { k = k < T ? k : T - 1; return (size_t)(D.reverse ? k : T - 1 - k) * B + bq; };
+    const float* p_c2 = w0 ? D.cst + row_of(2) * N + unit : dummy;
+    const float* p_hc2 = w1 ? D.hcst + row_of(2) * H + huq : dummy;
+    float c0 = *(w0 ? D.cst + row_of(0) * N + unit : dummy), c1 = *(w0 ? D.cst + row_of(1) * N + unit : dummy);
+    float hc0 = *(w1 ? D.hcst + row_of(0) * H + huq : dummy), hc1 = *(w1 ? D.hcst + row_of(1) * H + huq : dummy);
+    float n_c2 = 0.f, n_hc2 = 0.f;
+    // loads the step the pointers stand on
+    auto prefetch = [&]() {
+        n_m = *p_m;
+        n_g4 = *(const f32x4*)p_g;
+        n_a4 = *(const f32x4*)p_a;
+        n_dh4 = *(const f32x4*)(p_a + a_1);
+        n_dx4 = *(const f32x4*)(p_a + a_2);
+        n_x4 = *(const f32x4*)p_x;
+        n_dre = *p_dr;
+        n_hg4 = *(const f32x4*)p_hg;
+        n_c2 = *p_c2;
+        n_hc2 = *p_hc2;
     };
-    prefetch(0);
+    auto advance = [&](bool go) {
+        p_m += go ? s_m : 0; p_g += go ? s_g : 0; p_x += go ? s_g : 0; p_a += go ? s_a : 0;
+        p_dr += go ? s_dr : 0; p_hg += go ? s_hg : 0;
+    };
+    prefetch();
     STAMP_DECL
     for (int step = 0; step < T; ++step) {
         const int st = T - 1 - step;
@@ -534,8 +549,11 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         const float m = bvalid ? n_m : 0.f;
         const bool on = (m != 0.f);
         const f32x4 g4 = n_g4, a4 = n_a4, dh4 = n_dh4, dx4 = n_dx4, x4 = n_x4, hg4 = n_hg4;
-        const float c_new = n_cnew, c_prev = st > 0 ? n_cprev : 0.f, dre = bvalid ? n_dre : 0.f;
-        const float hc_new = n_hcnew, hc_prev = st > 0 ? n_hcprev : 0.f;
+        const float c_new = c0, c_prev = st > 0 ? c1 : 0.f, dre = bvalid ? n_dre : 0.f;
+        const float hc_new = hc0, hc_prev = st > 0 ? hc1 : 0.f;
+        advance(step + 1 < T);
+        prefetch();                                        // step+1's tensors, step+2's cell rows
+        p_c2 += (step + 3 < T) ? s_c : 0; p_hc2 += (step + 3 < T) ? s_hc : 0;
         STAMP(9);
 
         // ---- S1: main cell backward (wave 0)
@@ -558,7 +576,6 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             }
             da4 = dg4 * dh4;
             dd_h = dg4 * a4; dd_x = dg4 * x4;
-            STAMP(10);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dal[(q * 4 + k) * 16 + bl] = da4[k];
@@ -598,9 +615,6 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         STAMP(1);
         group_publish(gs);
         STAMP(2);
-        // next step's saved tensors: issued here, in the shadow of exchange 1 (the poll runs on the last
-        // wave, so these loads do not queue in front of its poll results)
-        prefetch(step + 1 < T ? step + 1 : step);
         if (wave == 0 && bvalid) {        // bulk outputs after the publish: off the critical path
             *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
             *(f32x4*)(D.dXp + row * 4 * N + col4) = dg4 * dx4;
@@ -699,6 +713,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             // tile [unit bl][batch q*4..q*4+3] of this wave
             st_sc1_f4(px_rs, (unsigned)(((((size_t)par * G + j) * 4 + wv) * 256 + bl * 16 + q * 4) * 4), acc);
         }
+        STAMP(10);
         group_publish(gs);
         STAMP(6);
         if (wave == 1 && hvalid && bvalid) *(f32x4*)(D.dXh + row * 4 * H + hu * 4) = dhg;
@@ -758,6 +773,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             }
             dhh_rec = v;
         }
+        c0 = c1; c1 = n_c2; hc0 = hc1; hc1 = n_hc2;
         STAMP(8);
         __syncthreads();
     }

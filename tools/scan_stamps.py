@@ -16,7 +16,7 @@ for it in range(2):
 net.check_status()
 L = _lib.lib()
 for bw, names in ((False, ['wait_h', 'ph1_mfma', 'epi_hyper', 'publish1', 'wait_hh', 'ph2_mfma', 'epi_main', 'publish2', '-', '-', '-', '-']),
-                  (True, ['S1_main', 'S2_mfma', 'publish1', 'wait1', 'S3_gather', 'S4_hyper', 'publish2', 'wait2', 'S5_mfma', 'prefetch', 'S1_math', 'da_mfma'])):
+                  (True, ['S1_main', 'S2_mfma', 'publish1', 'wait1', 'S3_gather', 'S4_hyper', 'publish2', 'wait2', 'S5_mfma', 'prefetch', 'da_mfma', 'bulk_st'])):
     need = L.asr_hyper_scan_ws_bytes(T, 16, 512, 128, 2, int(bw))
     ws = net._ws[('hyper', 0, bw)]
     raw = ws[need - 65536:need].view(torch.int64).cpu().numpy()[:256 * 12].reshape(256, 12)
