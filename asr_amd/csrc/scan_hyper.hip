@@ -43,8 +43,8 @@ struct HyperArgs {
     const float* mask; int msb, mst;
     HyperDir d[2];
     unsigned* sync;
-    float* rex;      // [ng][2][KS][64]
-    float* hex;      // [ng][2][G][64]
+    float* rex;      // [ng][2][KSP workgroups][16 b][4 units]   h_t   (all-gather)
+    float* hex;      // [ng][2][HSP groups of 4 hyper units][16 b][4]  hhat_t (all-gather)
     float* dax;      // [ng][2][G src][64 lanes][4]: da of the source's 16 gate columns (all-gather)
     float* px;       // [ng][2][G src][4 waves][16 units][16 b]: partial W_h.da tiles (R-way reduce)
     float* dhx;      // [ng][2][G dst][G src][UH*16]
@@ -91,7 +91,7 @@ __global__ void hyper_pack_kernel(const float* __restrict__ Wh, const float* __r
         const size_t n1 = (size_t)A.KSP * 64;
         for (size_t i = threadIdx.x; i < n1; i += blockDim.x) {
             const int e = i & 3, l = (i >> 2) & 63, s4 = (int)(i >> 8);
-            const int row = 4 * (4 * s4 + e) + (l >> 4), col = j * 16 + (l & 15);
+            const int row = 4 * (4 * s4 + (l >> 4)) + e, col = j * 16 + (l & 15);   // k = source workgroup, step e = its unit
             o[i] = row < N ? Wh[(size_t)row * 4 * N + col] : 0.f;
         }
         float* og = o + n1;
@@ -106,10 +106,10 @@ __global__ void hyper_pack_kernel(const float* __restrict__ Wh, const float* __r
             float v = 0.f;
             if (hu < H) {
                 if (s4g < A.KSP / 4) {
-                    const int row = 4 * (4 * s4g + e) + qq;
+                    const int row = 4 * (4 * s4g + qq) + e;
                     if (row < N) v = Whx[(size_t)row * 4 * H + col];
                 } else {
-                    const int row = 4 * (4 * (s4g - A.KSP / 4) + e) + qq;
+                    const int row = 4 * (4 * (s4g - A.KSP / 4) + qq) + e;
                     if (row < H) v = Whh[(size_t)row * 4 * H + col];
                 }
             }
@@ -120,7 +120,7 @@ __global__ void hyper_pack_kernel(const float* __restrict__ Wh, const float* __r
         for (size_t i = threadIdx.x; i < n3; i += blockDim.x) {
             const int e = i & 3, l = (i >> 2) & 63;
             const int s4 = (int)((i >> 8) % (A.HSP / 4)), tau = (int)((i >> 8) / (A.HSP / 4));
-            const int row = 4 * (4 * s4 + e) + (l >> 4);
+            const int row = 4 * (4 * s4 + (l >> 4)) + e;
             od[i] = row < H ? M[(size_t)row * 12 * N + (size_t)tau * 4 * N + j * 16 + (l & 15)] : 0.f;
         }
     } else {
@@ -209,15 +209,15 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         f32x4* dst = (f32x4*)smem;
         for (size_t i = tid; i < per_wg / 4; i += 256) dst[i] = src[i];
     }
-    float* rex = A.rex + (size_t)grp * 2 * KS * 64;
-    float* hex = A.hex + (size_t)grp * 2 * G * 64;
-    const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(2 * KS * 64 * 4));
-    const __amdgpu_buffer_rsrc_t hex_rs = make_rsrc_(hex, (unsigned)(2 * G * 64 * 4));
+    float* rex = A.rex + (size_t)grp * 2 * KSP * 64;
+    float* hex = A.hex + (size_t)grp * 2 * HSP * 64;
+    const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(2 * KSP * 64 * 4));
+    const __amdgpu_buffer_rsrc_t hex_rs = make_rsrc_(hex, (unsigned)(2 * HSP * 64 * 4));
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    // hhat element for MFMA k index (step sidx, lane q,bl): hyper unit hq = 4*sidx+q lives at
-    // [hq/UH][ (hq%UH)*16 + bl ]  ==  sidx*(256/UH) + lane constant   (UH in {1,2,4})
-    const unsigned hh_voff = 4u * (UH == 1 ? q * 64 + bl : UH == 2 ? (q >> 1) * 64 + (q & 1) * 16 + bl : q * 16 + bl);
-    const unsigned hh_sc = 4u * (256 / UH);
+    // Exchange layouts [block of 4 units][batch][unit in block]: MFMA k index q <-> block 4*s4+q, the 4
+    // MFMA steps of a group <-> the 4 units of the block, so a lane's B operands of one group are ONE
+    // 16-byte sc1 load (16-B accesses run at ~2x the per-byte rate of 4-B ones on this path)
+    const unsigned ex_voff = (unsigned)((q * 64 + bl * 4) * 4);
 
     const int unit = j * 4 + q;                  // wave 0: main unit of this lane
     const int col4 = unit * 4;
@@ -229,22 +229,40 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         cv_h = *(const f32x4*)(D.cvec + col4);
         cv_x = *(const f32x4*)(D.cvec + 4 * N + col4);
         cv_b = *(const f32x4*)(D.cvec + 8 * N + col4);
-        st_sc1(rex + (size_t)j * 64 + lane, 0.f);
     }
-    if (wave == 1) st_sc1(hex + (size_t)j * 64 + lane, 0.f);
+    // zero both parities of both exchange buffers, padding included (state 0 at step 0; padded blocks
+    // meet zero weights, but 0 x stale NaN would still poison the MFMA): the group's G workgroups
+    // share the work; the first wait below orders it before any reader and any later writer
+    for (int i = j * 256 + tid; i < 2 * KSP * 16; i += G * 256) st_sc1_f4(rex_rs, (unsigned)i * 16u, f32x4{0, 0, 0, 0});
+    for (int i = j * 256 + tid; i < 2 * HSP * 16; i += G * 256) st_sc1_f4(hex_rs, (unsigned)i * 16u, f32x4{0, 0, 0, 0});
     group_publish(gs);
 
     const int ks4 = KSP / 16, hs4 = HSP / 16;    // b128 groups per wave
+    // inputs of the step, loaded one step ahead through walking per-lane pointers; branch-free (every
+    // wave issues every load, non-owners read a dummy line) so that no join sits behind the loads
+    const bool w0 = (wv == 0), w1 = (wv == 1);
+    const int bq = bvalid ? b : (B - 1), huq = hvalid ? hu : 0;
+    const float* const dummy = D.wpack;
+    const int dt = D.reverse ? -1 : 1;
+    const size_t r00 = (size_t)(D.reverse ? T - 1 : 0) * B + bq;
+    const float* p_m = (w0 || w1) ? A.mask + (size_t)(D.reverse ? T - 1 : 0) * A.mst + (size_t)bq * A.msb : dummy;
+    const float* p_x = w0 ? D.xproj + r00 * 4 * N + col4 : dummy;
+    const float* p_xh = w1 ? D.xhproj + r00 * 4 * H + huq * 4 : dummy;
+    const int s_m = (w0 || w1) ? dt * A.mst : 0, s_x = w0 ? dt * B * 4 * N : 0, s_xh = w1 ? dt * B * 4 * H : 0;
+    float n_m = *p_m;
+    f32x4 n_x4 = *(const f32x4*)p_x, n_xh4 = *(const f32x4*)p_xh;
     STAMP_DECL
     for (int step = 0; step < T; ++step) {
         const int t = D.reverse ? T - 1 - step : step;
         const int par = step & 1;
         const size_t row = (size_t)t * B + b;
-        f32x4 x4 = {0, 0, 0, 0}, xh4 = {0, 0, 0, 0};
-        float m = 0.f;
-        if (bvalid && wave < 2) m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
-        if (wave == 0 && bvalid) x4 = *(const f32x4*)(D.xproj + row * 4 * N + col4);
-        if (wave == 1 && bvalid && hvalid) xh4 = *(const f32x4*)(D.xhproj + row * 4 * H + hu * 4);
+        const float m = bvalid ? n_m : 0.f;
+        const f32x4 x4 = n_x4, xh4 = n_xh4;
+        {
+            const bool go = step + 1 < T;
+            p_m += go ? s_m : 0; p_x += go ? s_x : 0; p_xh += go ? s_xh : 0;
+            n_m = *p_m; n_x4 = *(const f32x4*)p_x; n_xh4 = *(const f32x4*)p_xh;
+        }
         if (!group_wait(gs)) break;
         STAMP(0);
 
@@ -256,58 +274,58 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         f32x4 am0 = {0, 0, 0, 0}, am1 = {0, 0, 0, 0}, ag0 = {0, 0, 0, 0}, ag1 = {0, 0, 0, 0};
         const int ic = (bl < CR ? bl : CR - 1);
         const bool defer = (ks4 <= 8);
-        float bh[16], bv[32];
+        f32x4 bh[4], bv[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)(par * G * 256) + (unsigned)((wv * hs4) * 4 + i) * hh_sc);
+        for (int i = 0; i < 4; ++i)
+            bh[i] = ldb_sc1_f4(hex_rs, ex_voff, (unsigned)(par * HSP * 256) + (unsigned)(wv * hs4 + i) * 1024u);
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
-            bv[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * ks4) * 4 + i) * 256u);
+        for (int i = 0; i < 8; ++i)
+            bv[i] = ldb_sc1_f4(rex_rs, ex_voff, (unsigned)(par * KSP * 256) + (unsigned)(wv * ks4 + i) * 1024u);
 #pragma unroll
         for (int g4 = 0; g4 < 8; ++g4) {
             if (g4 < ks4) {
                 const int s4 = wave * ks4 + g4;
                 const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
-                ag0 = mfma4(gv[0], bv[g4 * 4 + 0], ag0); ag1 = mfma4(gv[1], bv[g4 * 4 + 1], ag1);
-                ag0 = mfma4(gv[2], bv[g4 * 4 + 2], ag0); ag1 = mfma4(gv[3], bv[g4 * 4 + 3], ag1);
+                ag0 = mfma4(gv[0], bv[g4][0], ag0); ag1 = mfma4(gv[1], bv[g4][1], ag1);
+                ag0 = mfma4(gv[2], bv[g4][2], ag0); ag1 = mfma4(gv[3], bv[g4][3], ag1);
                 if (!defer) {
                     const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
-                    am0 = mfma4(av[0], bv[g4 * 4 + 0], am0); am1 = mfma4(av[1], bv[g4 * 4 + 1], am1);
-                    am0 = mfma4(av[2], bv[g4 * 4 + 2], am0); am1 = mfma4(av[3], bv[g4 * 4 + 3], am1);
+                    am0 = mfma4(av[0], bv[g4][0], am0); am1 = mfma4(av[1], bv[g4][1], am1);
+                    am0 = mfma4(av[2], bv[g4][2], am0); am1 = mfma4(av[3], bv[g4][3], am1);
                 }
             }
         }
         for (int c0 = 8; c0 < ks4; c0 += 8) {           // N > 512: further chunks, main + hyper together
-            float bw[32];
+            f32x4 bw[8];
 #pragma unroll
-            for (int i = 0; i < 32; ++i)
-                bw[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * ks4 + c0) * 4 + i) * 256u);
+            for (int i = 0; i < 8; ++i)
+                bw[i] = ldb_sc1_f4(rex_rs, ex_voff, (unsigned)(par * KSP * 256) + (unsigned)(wv * ks4 + c0 + i) * 1024u);
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
                 if (c0 + g4 < ks4) {
                     const int s4 = wave * ks4 + c0 + g4;
                     const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
                     const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
-                    am0 = mfma4(av[0], bw[g4 * 4 + 0], am0); ag0 = mfma4(gv[0], bw[g4 * 4 + 0], ag0);
-                    am1 = mfma4(av[1], bw[g4 * 4 + 1], am1); ag1 = mfma4(gv[1], bw[g4 * 4 + 1], ag1);
-                    am0 = mfma4(av[2], bw[g4 * 4 + 2], am0); ag0 = mfma4(gv[2], bw[g4 * 4 + 2], ag0);
-                    am1 = mfma4(av[3], bw[g4 * 4 + 3], am1); ag1 = mfma4(gv[3], bw[g4 * 4 + 3], ag1);
+                    am0 = mfma4(av[0], bw[g4][0], am0); ag0 = mfma4(gv[0], bw[g4][0], ag0);
+                    am1 = mfma4(av[1], bw[g4][1], am1); ag1 = mfma4(gv[1], bw[g4][1], ag1);
+                    am0 = mfma4(av[2], bw[g4][2], am0); ag0 = mfma4(gv[2], bw[g4][2], ag0);
+                    am1 = mfma4(av[3], bw[g4][3], am1); ag1 = mfma4(gv[3], bw[g4][3], ag1);
                 }
             }
         }
         for (int h0 = 0; h0 < hs4; h0 += 4) {
             if (h0 > 0) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)(par * G * 256) + (unsigned)((wv * hs4 + h0) * 4 + i) * hh_sc);
+                for (int i = 0; i < 4; ++i)
+                    bh[i] = ldb_sc1_f4(hex_rs, ex_voff, (unsigned)(par * HSP * 256) + (unsigned)(wv * hs4 + h0 + i) * 1024u);
             }
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 if (h0 + g4 < hs4) {
                     const int s4 = wave * hs4 + h0 + g4;
                     const f32x4 gv = *(const f32x4*)(Wg + (((size_t)(KSP / 4 + s4) * 4 + q) * CR + ic) * 4);
-                    ag0 = mfma4(gv[0], bh[g4 * 4 + 0], ag0); ag1 = mfma4(gv[1], bh[g4 * 4 + 1], ag1);
-                    ag0 = mfma4(gv[2], bh[g4 * 4 + 2], ag0); ag1 = mfma4(gv[3], bh[g4 * 4 + 3], ag1);
+                    ag0 = mfma4(gv[0], bh[g4][0], ag0); ag1 = mfma4(gv[1], bh[g4][1], ag1);
+                    ag0 = mfma4(gv[2], bh[g4][2], ag0); ag1 = mfma4(gv[3], bh[g4][3], ag1);
                 }
             }
         }
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
             const float hc_new = hf * hc + hi * hgc;
             const float hh_new = ho * tanhf_(hc_new);
             if (m != 0.f && hvalid) { hc = hc_new; hh = hh_new; }
-            st_sc1(hex + ((size_t)(par ^ 1) * G + j) * 64 + lane, hvalid ? hh : 0.f);
+            if (hvalid) st_sc1(hex + ((size_t)(par ^ 1) * HSP * 64) + ((size_t)(hu >> 2) * 16 + bl) * 4 + (hu & 3), hh);
             hsave = f32x4{hi, hf, hgc, ho};
         }
         STAMP(2);
@@ -340,8 +358,8 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
             for (int g4 = 0; g4 < 8; ++g4) {
                 if (g4 < ks4) {
                     const f32x4 av = *(const f32x4*)(Wm + ((size_t)(wave * ks4 + g4) * 64 + lane) * 4);
-                    am0 = mfma4(av[0], bv[g4 * 4 + 0], am0); am1 = mfma4(av[1], bv[g4 * 4 + 1], am1);
-                    am0 = mfma4(av[2], bv[g4 * 4 + 2], am0); am1 = mfma4(av[3], bv[g4 * 4 + 3], am1);
+                    am0 = mfma4(av[0], bv[g4][0], am0); am1 = mfma4(av[1], bv[g4][1], am1);
+                    am0 = mfma4(av[2], bv[g4][2], am0); am1 = mfma4(av[3], bv[g4][3], am1);
                 }
             }
             // slot 0 is free here: its last reader (wave 0, previous step's main epilogue) has passed
@@ -365,10 +383,10 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         // ---- phase 2: d_h, d_x, bias = hhat_t . M  (3 tiles), then the main cell
         f32x4 ad[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         for (int h0 = 0; h0 < hs4; h0 += 4) {
-            float bh[16];
+            f32x4 bh[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                bh[i] = ldb_sc1(hex_rs, hh_voff, (unsigned)((par ^ 1) * G * 256) + (unsigned)((wv * hs4 + h0) * 4 + i) * hh_sc);
+            for (int i = 0; i < 4; ++i)
+                bh[i] = ldb_sc1_f4(hex_rs, ex_voff, (unsigned)((par ^ 1) * HSP * 256) + (unsigned)(wv * hs4 + h0 + i) * 1024u);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 if (h0 + g4 < hs4) {
@@ -377,7 +395,7 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
                     for (int tau = 0; tau < 3; ++tau) {
                         const f32x4 dv = *(const f32x4*)(Wd + (((size_t)tau * (HSP / 4) + s4) * 64 + lane) * 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ad[tau] = mfma4(dv[e], bh[g4 * 4 + e], ad[tau]);
+                        for (int e = 0; e < 4; ++e) ad[tau] = mfma4(dv[e], bh[g4][e], ad[tau]);
                     }
                 }
             }
@@ -400,7 +418,11 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
             const float c_new = fg * c + ig * gg;
             const float r_new = og * tanhf_(c_new);
             if (m != 0.f) { c = c_new; r = r_new; }
-            st_sc1(rex + ((size_t)(par ^ 1) * KS + j) * 64 + lane, r);
+            {
+                const float r1 = __shfl(r, bl + 16), r2 = __shfl(r, bl + 32), r3 = __shfl(r, bl + 48);
+                if (q == 0)
+                    st_sc1_f4(rex_rs, (unsigned)((((size_t)(par ^ 1) * KSP + j) * 64 + bl * 4) * 4), f32x4{r, r1, r2, r3});
+            }
             gsave = f32x4{ig, fg, gg, og};
         }
         STAMP(6);
@@ -795,7 +817,7 @@ extern "C" size_t asr_hyper_scan_ws_bytes(int T, int B, int N, int H, int ndir, 
     hyper_dims(N, H, &A);
     const size_t ng = (size_t)ndir * ((B + 7) / 8);     // sized for the 8-row chunking
     size_t bytes = ng * SYNC_STRIDE * 4;
-    bytes += ng * 2 * A.KS * 64 * 4 + ng * 2 * A.G * 64 * 4;
+    bytes += ng * 2 * A.KSP * 64 * 4 + ng * 2 * A.HSP * 64 * 4;
     if (backward) {
         bytes += ng * 2 * (size_t)A.G * 256 * 4;
         bytes += ng * 2 * (size_t)A.G * 1024 * 4;
@@ -844,8 +866,8 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     const size_t ng = (size_t)d->ndir * ((d->B + 7) / 8);
     char* p = (char*)ws;
     A.sync = (unsigned*)p;  p += ng * SYNC_STRIDE * 4;
-    A.rex = (float*)p;      p += ng * 2 * A.KS * 64 * 4;
-    A.hex = (float*)p;      p += ng * 2 * A.G * 64 * 4;
+    A.rex = (float*)p;      p += ng * 2 * A.KSP * 64 * 4;
+    A.hex = (float*)p;      p += ng * 2 * A.HSP * 64 * 4;
     A.dax = A.px = A.dhx = A.dgx = nullptr;
     if (backward) {
         A.dax = (float*)p;  p += ng * 2 * (size_t)A.G * 256 * 4;
