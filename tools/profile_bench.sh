@@ -12,3 +12,5 @@ timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 find $OUT -name "*.csv" | head -20
+python3 $R/tools/summarize_prof.py $OUT $TAG $R/gpurun_out/prof_summary_$TAG
+ls -la $R/gpurun_out/prof_summary_$TAG

@@ -1,0 +1,49 @@
+"""Condenses the rocprofv3 output of tools/profile_bench.sh into the small files kept under profiles/:
+  <tag>_bench_kernel_stats.csv   the --stats kernel table as rocprofv3 wrote it
+  <tag>_bench_pmc_hbm.csv        per kernel: launches, FETCH_SIZE and WRITE_SIZE (KB, average per launch)
+  <tag>_pmc_hyper_scan_bwd.json  the dominant kernel's two figures, read by bench.py for roofline.traffic
+usage: python tools/summarize_prof.py <prof_dir> <tag> <out_dir>"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+
+def pmc(dirname, counter):
+    acc = defaultdict(lambda: [0, 0.0])       # kernel -> [dispatches, sum]
+    disp = defaultdict(set)
+    for f in glob.glob(os.path.join(dirname, '**', '*counter_collection.csv'), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get('Counter_Name') != counter:
+                    continue
+                k = r['Kernel_Name'].split('(')[0]
+                disp[k].add((f, r['Dispatch_Id']))
+                acc[k][1] += float(r['Counter_Value'])
+    return {k: (len(disp[k]), v[1] / max(len(disp[k]), 1)) for k, v in acc.items()}
+
+
+def main():
+    prof, tag, out = sys.argv[1:4]
+    os.makedirs(out, exist_ok=True)
+    st = glob.glob(os.path.join(prof, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(out, tag + '_bench_kernel_stats.csv'))
+    fe = pmc(os.path.join(prof, 'pmc_fetch'), 'FETCH_SIZE')
+    wr = pmc(os.path.join(prof, 'pmc_write'), 'WRITE_SIZE')
+    names = sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, (0, 0))[0] * fe.get(k, (0, 0))[1]))
+    with open(os.path.join(out, tag + '_bench_pmc_hbm.csv'), 'w') as fh:
+        fh.write('kernel,launches,FETCH_SIZE_KB_avg_per_launch,WRITE_SIZE_KB_avg_per_launch\n')
+        for k in names:
+            fh.write('"%s",%d,%.1f,%.1f\n' % (k, max(fe.get(k, (0, 0))[0], wr.get(k, (0, 0))[0]),
+                                              fe.get(k, (0, 0))[1], wr.get(k, (0, 0))[1]))
+    for kname in ('hyper_scan_bwd_kernel', 'hyper_scan_fwd_kernel'):
+        if kname in fe and kname in wr:
+            json.dump({'kernel': kname,
+                       'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1, ' + tag,
+                       'fetch_size_kb_per_launch': fe[kname][1], 'write_size_kb_per_launch': wr[kname][1],
+                       'note': 'bytes = KB*1024; FETCH_SIZE on gfx950 counts wide coalesced reads at half their bytes '
+                               '(MI355X_MICROARCH.md HBM): traffic_bytes = 2*FETCH + WRITE is the upper estimate, FETCH + WRITE the lower'},
+                      open(os.path.join(out, '%s_pmc_%s.json' % (tag, kname.replace('_kernel', ''))), 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
