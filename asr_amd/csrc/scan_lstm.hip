@@ -53,7 +53,7 @@ struct LstmScanArgs {
     const float* mask; int msb, mst;
     LstmDir d[2];
     unsigned* sync;          // [ngroups][SYNC_STRIDE]
-    float* rex;              // [ngroups][2][KS][64]
+    float* rex;              // [ngroups][2][KSP tiles][16 b][4 units]
     float* sta;              // [ngroups][2][KS][4 gates][32]  (gate 0 only unless per_gate)
     float* stc;              // [ngroups][2][KS][32]
     float* dex;              // [ngroups][2][KS dst][G src][64]      (backward)
@@ -61,7 +61,8 @@ struct LstmScanArgs {
 
 // ------------------------------------------------------------------------------------------------
 // weight packing.  W (N x 4N) row-major, gate-interleaved columns.
-//  mode 0 (forward A-fragments):  out[tile][s4][l][e] = W[4*(4*s4+e) + (l>>4)][tile*16 + (l&15)]
+//  mode 0 (forward A-fragments):  out[tile][s4][l][e] = W[4*(4*s4+(l>>4)) + e][tile*16 + (l&15)]
+//          (MFMA k index l>>4 <-> source tile 4*s4+k, the 4 steps e of a group <-> the tile's 4 units)
 //  mode 1 (backward A-fragments): out[tile][kt][l][e] = W[kt*16 + (l&15)][tile*16 + 4*e + (l>>4)]
 // rows/steps beyond N are zero.
 __global__ void lstm_pack_kernel(const float* __restrict__ W, int N, int KS, int KSP, int KT, int mode,
@@ -74,7 +75,7 @@ __global__ void lstm_pack_kernel(const float* __restrict__ W, int N, int KS, int
         const int r = (int)(i % per_tile);
         const int e = r & 3, l = (r >> 2) & 63, blk = r >> 8;
         int row, col;
-        if (mode == 0) { row = 4 * (4 * blk + e) + (l >> 4); col = tile * 16 + (l & 15); }
+        if (mode == 0) { row = 4 * (4 * blk + (l >> 4)) + e; col = tile * 16 + (l & 15); }
         else           { row = blk * 16 + (l & 15);          col = tile * 16 + 4 * e + (l >> 4); }
         out[i] = row < N ? W[(size_t)row * 4 * N + col] : 0.0f;
     }
@@ -174,11 +175,14 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         f32x4* dst = (f32x4*)Wl;
         for (int i = tid; i < UT * KSP * 16; i += 256) dst[i] = src[i];
     }
-    float* rex = A.rex + (size_t)grp * 2 * KS * 64;
+    float* rex = A.rex + (size_t)grp * 2 * KSP * 64;
     float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 128 : nullptr;
     float* stc = A.stc ? A.stc + (size_t)grp * 2 * KS * 32 : nullptr;
-    const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(2 * KS * 64 * 4));
+    const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(2 * KSP * 64 * 4));
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // exchange layout [tile][batch][unit]: a lane's B operands of one group of 4 MFMA steps are ONE
+    // 16-byte sc1 load, a tile's r is one 16-byte sc1 store per batch row
+    const unsigned ex_voff = (unsigned)((q * 64 + bl * 4) * 4);
 
     // epilogue-wave state: wave ut < UT owns tile (j*UT+ut); lane (q,bl) owns unit q of it for row bl
     const int tile = j * UT + (wave < UT ? wave : 0);
@@ -188,23 +192,42 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     if (wave < UT) {
         if (bvalid && D.c0) c = D.c0[(size_t)b * N + unit];
         if (bvalid && D.r0) r = D.r0[(size_t)b * N + unit];
-        st_sc1(rex + (size_t)tile * 64 + lane, r);       // parity 0 holds r_{-1}
+        const float r1 = __shfl(r, bl + 16), r2 = __shfl(r, bl + 32), r3 = __shfl(r, bl + 48);
+        if (q == 0) st_sc1_f4(rex_rs, (unsigned)(((size_t)tile * 64 + bl * 4) * 4), f32x4{r, r1, r2, r3});   // parity 0 holds r_{-1}
     }
+    if (j == 0)                                          // padded tiles (zero weights) must not hold NaNs
+        for (int i = tid; i < 2 * (KSP - KS) * 16; i += 256) {
+            const int pr = i / ((KSP - KS) * 16), o = i % ((KSP - KS) * 16);
+            st_sc1_f4(rex_rs, (unsigned)((((size_t)pr * KSP + KS) * 16 + o) * 16), f32x4{0, 0, 0, 0});
+        }
     float ac_u = 1.f, bc_u = 0.f;
     if (A.cell_ln) { ac_u = D.alpha_c[unit]; bc_u = D.beta_c[unit]; }
     group_publish(gs);
 
     const int s4_per_wave = KSP / 16;                    // groups of 4 MFMA k-steps per wave
+    // inputs of the step, loaded one step ahead through walking per-lane pointers; branch-free (every
+    // wave issues the loads, non-owners read a dummy line), because hipcc waits for a load at the first
+    // control-flow join behind it
+    const bool own = wv < UT;
+    const int bq = bvalid ? b : (B - 1);
+    const float* const dummy = D.wpack;
+    const int dt = D.reverse ? -1 : 1;
+    const int t0 = D.reverse ? T - 1 : 0;
+    const float* p_x = own ? D.xin + ((size_t)t0 * B + bq) * 4 * N + col4 : dummy;
+    const float* p_m = own ? A.mask + (size_t)bq * A.msb + (size_t)t0 * A.mst : dummy;
+    const int s_x = own ? dt * B * 4 * N : 0, s_m = own ? dt * A.mst : 0;
+    f32x4 n_x4 = *(const f32x4*)p_x;
+    float n_m = *p_m;
     for (int step = 0; step < T; ++step) {
         const int t = D.reverse ? T - 1 - step : step;
         const int par = step & 1;
         const size_t row = (size_t)t * B + b;
-        // prefetch what does not depend on the exchange
-        f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
-        float m = 0.f;
-        if (wave < UT && bvalid) {
-            x4 = *(const f32x4*)(D.xin + row * 4 * N + col4);
-            m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
+        const f32x4 x4 = n_x4;
+        const float m = (own && bvalid) ? n_m : 0.f;
+        {
+            const bool go = step + 1 < T;
+            p_x += go ? s_x : 0; p_m += go ? s_m : 0;
+            n_x4 = *(const f32x4*)p_x; n_m = *p_m;
         }
         if (!group_wait(gs)) break;
 
@@ -215,10 +238,10 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         // request a whole chunk of B operands before its first MFMA: the exchange-buffer latency is
         // paid once per chunk instead of once per k-step
         for (int c0 = 0; c0 < s4_per_wave; c0 += 8) {
-            float bv[32];
+            f32x4 bv[8];
 #pragma unroll
-            for (int i = 0; i < 32; ++i)   // rows >= N carry zero weights; beyond the buffer reads 0
-                bv[i] = ldb_sc1(rex_rs, lane * 4u, (unsigned)(par * KS * 256) + (unsigned)((wv * s4_per_wave + c0) * 4 + i) * 256u);
+            for (int i = 0; i < 8; ++i)    // tiles >= KS carry zero weights (and zeroed payload)
+                bv[i] = ldb_sc1_f4(rex_rs, ex_voff, (unsigned)(par * KSP * 256) + (unsigned)(wv * s4_per_wave + c0 + i) * 1024u);
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
                 if (c0 + g4 < s4_per_wave) {
@@ -226,10 +249,10 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
 #pragma unroll
                     for (int u = 0; u < UT; ++u) {
                         const f32x4 av = *(const f32x4*)(Wl + (((size_t)u * (KSP / 4) + s4) * 64 + lane) * 4);
-                        acc0[u] = mfma4(av[0], bv[g4 * 4 + 0], acc0[u]);
-                        acc1[u] = mfma4(av[1], bv[g4 * 4 + 1], acc1[u]);
-                        acc0[u] = mfma4(av[2], bv[g4 * 4 + 2], acc0[u]);
-                        acc1[u] = mfma4(av[3], bv[g4 * 4 + 3], acc1[u]);
+                        acc0[u] = mfma4(av[0], bv[g4][0], acc0[u]);
+                        acc1[u] = mfma4(av[1], bv[g4][1], acc1[u]);
+                        acc0[u] = mfma4(av[2], bv[g4][2], acc0[u]);
+                        acc1[u] = mfma4(av[3], bv[g4][3], acc1[u]);
                     }
                 }
             }
@@ -320,7 +343,11 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         if (wave < UT) {
             const float r_new = og * tanhf_(outcell);
             if (m != 0.f) { c = c_new; r = r_new; }
-            st_sc1(rex + ((size_t)(par ^ 1) * KS + tile) * 64 + lane, r);
+            {
+                const float r1 = __shfl(r, bl + 16), r2 = __shfl(r, bl + 32), r3 = __shfl(r, bl + 48);
+                if (q == 0)
+                    st_sc1_f4(rex_rs, (unsigned)((((size_t)(par ^ 1) * KSP + tile) * 64 + bl * 4) * 4), f32x4{r, r1, r2, r3});
+            }
             if (bvalid) {
                 D.r_out[row * D.ld_r + unit] = r;
                 D.cst[row * N + unit] = c;
@@ -566,7 +593,7 @@ extern "C" size_t asr_lstm_scan_ws_bytes(int T, int B, int N, int ndir, int back
     const int nchunk = (B + 15) / 16;
     const size_t ng = (size_t)ndir * nchunk;
     size_t bytes = ng * SYNC_STRIDE * 4;
-    bytes += ng * 2 * KS * 64 * 4;            // rex
+    bytes += ng * 2 * KSP * 64 * 4;           // rex
     bytes += 5 * ng * 2 * KS * 32 * 4;        // sta (x4 for per-gate LN), stc
     if (backward) bytes += ng * 2 * (size_t)KS * KS * 64 * 4;   // dex (G <= KS)
     return bytes + 1024;
@@ -616,7 +643,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     char* p = (char*)ws;
     const size_t ng = (size_t)d->ndir * nchunk_total;
     A.sync = (unsigned*)p;                         p += ng * SYNC_STRIDE * 4;
-    A.rex = (float*)p;                             p += ng * 2 * A.KS * 64 * 4;
+    A.rex = (float*)p;                             p += ng * 2 * A.KSP * 64 * 4;
     A.sta = (float*)p;                             p += ng * 2 * A.KS * 128 * 4;
     A.stc = (float*)p;                             p += ng * 2 * A.KS * 32 * 4;
     A.dex = backward ? (float*)p : nullptr;

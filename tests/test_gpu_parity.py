@@ -138,7 +138,7 @@ def test_ln_lstmp_model_medium():
                                         device=_dev(), seed=3)
     perturb_params(net, 7, 0.03)
     b = make_batch(np.random.default_rng(8), 16, 50, 23, 17)
-    run_case(net, b)
+    run_case(net, b, calibrate=True)      # LN stack over T=50: bound by 3x its own fp32 noise floor
 
 
 def test_ivector_cond_ln_model():
