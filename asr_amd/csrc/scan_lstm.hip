@@ -412,27 +412,59 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
     float dc = 0.f, dr_pass = 0.f;
     __syncthreads();
 
+    // Saved tensors of a step are loaded one step ahead through walking per-lane pointers, branch-free
+    // (every wave issues every load; non-owners, absent tensors and invalid batch rows read a dummy
+    // line / a clamped row): hipcc waits for a load at the first control-flow join behind it, which put
+    // the HBM latency of these loads in front of every step.  The cell rows are read once, two steps
+    // ahead (c_prev of backward step s is the cell row of step s+1).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool own = wv < UT;
+    const bool lnp = own && A.ln_kind, lnpg = lnp && A.per_gate, lnrow = lnp && !A.per_gate, cln = own && A.cell_ln;
+    const int bq = bvalid ? b : (B - 1);
+    const float* const dummy = D.wpack;
+    const int dt = D.reverse ? 1 : -1;
+    auto row_of = [&](int k) { k = k < T ? k : T - 1; return (size_t)(D.reverse ? k : T - 1 - k) * B + bq; };
+    const size_t r00 = row_of(0);
+    const float* p_m = own ? A.mask + (size_t)bq * A.msb + (size_t)(D.reverse ? 0 : T - 1) * A.mst : dummy;
+    const float* p_g = own ? D.gates + r00 * 4 * N + col4 : dummy;
+    const float* p_dr = own ? D.dr_ext + r00 * D.ld_dr + unit : dummy;
+    const float* p_ah = lnp ? D.ahat + r00 * 4 * N + col4 : dummy;
+    const float* p_ra4 = lnpg ? D.rs_a + r00 * 4 : dummy;
+    const float* p_ra = lnrow ? D.rs_a + r00 : dummy;
+    const float* p_ch = cln ? D.chat + r00 * N + unit : dummy;
+    const float* p_rc = cln ? D.rs_c + r00 : dummy;
+    const float* p_c2 = own ? D.cst + row_of(2) * N + unit : dummy;
+    const int s_m = own ? dt * A.mst : 0, s_g = own ? dt * B * 4 * N : 0, s_dr = own ? dt * B * D.ld_dr : 0;
+    const int s_ah = lnp ? dt * B * 4 * N : 0, s_ra4 = lnpg ? dt * B * 4 : 0, s_ra = lnrow ? dt * B : 0;
+    const int s_ch = cln ? dt * B * N : 0, s_rc = cln ? dt * B : 0, s_c = own ? dt * B * N : 0;
+    float c0v = *(own ? D.cst + row_of(0) * N + unit : dummy), c1v = *(own ? D.cst + row_of(1) * N + unit : dummy);
+    const float c_init = *((own && D.c0) ? D.c0 + (size_t)bq * N + unit : dummy);
+    const bool has_c0 = D.c0 != nullptr;
+    float n_m, n_dre, n_ra, n_ch, n_rc, n_c2;
+    f32x4 n_g4, n_ah4, n_ra4;
+    auto prefetch = [&]() {
+        n_m = *p_m; n_g4 = *(const f32x4*)p_g; n_dre = *p_dr;
+        n_ah4 = *(const f32x4*)p_ah; n_ra4 = *(const f32x4*)p_ra4; n_ra = *p_ra;
+        n_ch = *p_ch; n_rc = *p_rc; n_c2 = *p_c2;
+    };
+    prefetch();
+
     for (int step = 0; step < T; ++step) {
         const int st = T - 1 - step;                     // forward iteration index
         const int t = D.reverse ? T - 1 - st : st;
-        const int tprev = D.reverse ? t + 1 : t - 1;     // valid when st > 0
         const int par = step & 1;
         const size_t row = (size_t)t * B + b;
-        const size_t rowp = (size_t)tprev * B + b;
-        f32x4 g4 = {0, 0, 0, 0}, ah4 = {0, 0, 0, 0}, rs_a4 = {0, 0, 0, 0};
-        float m = 0.f, c_new = 0.f, c_prev = 0.f, dre = 0.f, chat_v = 0.f, rs_a = 0.f, rs_c = 0.f;
-        if (wave < UT && bvalid) {
-            m = A.mask[(size_t)b * A.msb + (size_t)t * A.mst];
-            g4 = *(const f32x4*)(D.gates + row * 4 * N + col4);
-            c_new = D.cst[row * N + unit];
-            c_prev = st > 0 ? D.cst[rowp * N + unit] : (D.c0 ? D.c0[(size_t)b * N + unit] : 0.f);
-            dre = D.dr_ext[row * D.ld_dr + unit];
-            if (A.ln_kind) {
-                ah4 = *(const f32x4*)(D.ahat + row * 4 * N + col4);
-                if (A.per_gate) rs_a4 = *(const f32x4*)(D.rs_a + row * 4);
-                else rs_a = D.rs_a[row];
-            }
-            if (A.cell_ln) { chat_v = D.chat[row * N + unit]; rs_c = D.rs_c[row]; }
+        const bool live = own && bvalid;
+        const float m = live ? n_m : 0.f;
+        const f32x4 g4 = n_g4, ah4 = n_ah4, rs_a4 = n_ra4;
+        const float c_new = c0v, c_prev = st > 0 ? c1v : (has_c0 ? c_init : 0.f);
+        const float dre = live ? n_dre : 0.f, rs_a = n_ra, chat_v = n_ch, rs_c = n_rc;
+        {
+            const bool go = step + 1 < T;
+            p_m += go ? s_m : 0; p_g += go ? s_g : 0; p_dr += go ? s_dr : 0; p_ah += go ? s_ah : 0;
+            p_ra4 += go ? s_ra4 : 0; p_ra += go ? s_ra : 0; p_ch += go ? s_ch : 0; p_rc += go ? s_rc : 0;
+            prefetch();
+            p_c2 += (step + 3 < T) ? s_c : 0;
         }
         // 1. gather dr contributions published by the previous backward step
         float dr_sum = 0.f;
@@ -564,6 +596,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             }
             group_publish(gs);
         }
+        c0v = c1v; c1v = n_c2;
     }
 }
 
