@@ -186,6 +186,7 @@ extern "C" int asr_hyper_pack_w(const float* Wh, const float* Whx, const float* 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t per_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     const int N = A.N, H = A.H, UH = A.UH, CR = 4 * UH, KS = A.KS, KSP = A.KSP, HS = A.HS, HSP = A.HSP;
     const int T = A.T, B = A.B, G = A.G;
     float* Wm = smem;                                           // [KSP/4][64][4]
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
 #define DAB 8      // da blocks per wave put in flight early (covers NBW <= 8, e.g. G = 128 with R = 8)
 __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t per_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __builtin_amdgcn_s_setprio(3);
     const int N = A.N, H = A.H, UH = A.UH, HT = A.HT;
     const int T = A.T, B = A.B, G = A.G;
     const int S4P = ((H + 15) / 16) * 16;
