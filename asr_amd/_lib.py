@@ -60,6 +60,8 @@ _SIGS = {
     'asr_reduce_sum': (i32, [fp, sz, fp, i32, fp]),
     'asr_adam_step': (i32, [fp, fp, fp, fp, sz, f32, f32, f32, f32, fp, i32, fp, fp]),
     'asr_sqsum': (i32, [fp, sz, fp, i32, fp, fp]),
+    'asr_opt_step': (i32, [i32, fp, fp, fp, fp, sz, f32, f32, f32, f32, fp, fp]),
+    'asr_norm_clip_mult': (i32, [fp, f32, f32, fp, fp]),
     'asr_lstm_pack_floats': (sz, [i32, i32]),
     'asr_lstm_pack_w': (i32, [fp, i32, i32, fp, fp]),
     'asr_lstm_scan_ws_bytes': (sz, [i32, i32, i32, i32, i32]),

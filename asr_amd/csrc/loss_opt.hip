@@ -187,3 +187,102 @@ extern "C" int asr_sqsum(const float* g, size_t n, float* out, int want_sqrt, fl
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------- the other optimisers of
+// libs/lasagne_libs/updates.py (sgd :64-92, apply_momentum :95-149, apply_nesterov_momentum :191-251,
+// adagrad :298-363, rmsprop :366-433, adadelta :436-531, adam :534-618, adamax :621-698) as ONE
+// elementwise pass over the flat parameter buffer.  `gscale` (device scalar or null) multiplies every
+// gradient first: the multiplier of total_norm_constraint (:781-855), so that clipping by the global
+// norm needs no host round trip.
+//   kind 0 sgd        p -= lr g
+//        1 momentum   v = h1 v - lr g;            p += v
+//        2 nesterov   v = h1 v - lr g;            p += h1 v - lr g
+//        3 adagrad    a += g^2;                   p -= lr g / sqrt(a + eps)
+//        4 rmsprop    a = h1 a + (1-h1) g^2;      p -= lr g / sqrt(a + eps)
+//        5 adadelta   a = h1 a + (1-h1) g^2; u = g sqrt(d + eps)/sqrt(a + eps); p -= lr u; d = h1 d + (1-h1) u^2
+//        6 adamax     m = h1 m + (1-h1) g; u = max(h2 u, |g|);  p -= lr m / (u + eps)     (lr = a_t)
+//        7 adam       m = h1 m + (1-h1) g; v = h2 v + (1-h2) g^2; p -= lr m / (sqrt(v) + eps) (lr = a_t)
+template <int KIND>
+__device__ __forceinline__ void opt_elem(float& p, float g, float& s1, float& s2, float lr, float h1, float h2,
+                                         float eps) {
+    if (KIND == 0) { p = p - lr * g; }
+    else if (KIND == 1) { s1 = h1 * s1 - lr * g; p = p + s1; }
+    else if (KIND == 2) { s1 = h1 * s1 - lr * g; p = p + (h1 * s1 - lr * g); }
+    else if (KIND == 3) { s1 = s1 + g * g; p = p - lr * g / sqrtf(s1 + eps); }
+    else if (KIND == 4) { s1 = h1 * s1 + (1.f - h1) * g * g; p = p - lr * g / sqrtf(s1 + eps); }
+    else if (KIND == 5) {
+        s1 = h1 * s1 + (1.f - h1) * g * g;
+        const float u = g * sqrtf(s2 + eps) / sqrtf(s1 + eps);
+        p = p - lr * u;
+        s2 = h1 * s2 + (1.f - h1) * u * u;
+    }
+    else if (KIND == 6) { s1 = h1 * s1 + (1.f - h1) * g; s2 = fmaxf(h2 * s2, fabsf(g)); p = p - lr * s1 / (s2 + eps); }
+    else { s1 = h1 * s1 + (1.f - h1) * g; s2 = h2 * s2 + (1.f - h2) * g * g; p = p - lr * s1 / (sqrtf(s2) + eps); }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ s1, float* __restrict__ s2, size_t n,
+                                                       float lr, float h1, float h2, float eps,
+                                                       const float* __restrict__ gscale) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    constexpr bool U1 = KIND >= 1, U2 = KIND >= 5;
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i] * gs;
+        f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (U1) a = ((f32x4*)s1)[i];
+        if (U2) b = ((f32x4*)s2)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pv[e], ae = a[e], be = b[e];
+            opt_elem<KIND>(pe, gv[e], ae, be, lr, h1, h2, eps);
+            pv[e] = pe; a[e] = ae; b[e] = be;
+        }
+        ((f32x4*)p)[i] = pv;
+        if (U1) ((f32x4*)s1)[i] = a;
+        if (U2) ((f32x4*)s2)[i] = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float pe = p[i], ae = U1 ? s1[i] : 0.f, be = U2 ? s2[i] : 0.f;
+        opt_elem<KIND>(pe, g[i] * gs, ae, be, lr, h1, h2, eps);
+        p[i] = pe;
+        if (U1) s1[i] = ae;
+        if (U2) s2[i] = be;
+    }
+}
+
+extern "C" int asr_opt_step(int kind, float* p, const float* g, float* s1, float* s2, size_t n, float lr, float h1,
+                            float h2, float eps, const float* gscale, hipStream_t stream) {
+    if (kind < 0 || kind > 7 || !p || !g) return ASR_ERR_ARG;
+    if (kind >= 1 && !s1) return ASR_ERR_ARG;
+    if (kind >= 5 && !s2) return ASR_ERR_ARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) return ASR_ERR_ARG;
+    if (n == 0) return ASR_OK;
+#define OPT_(K) hipLaunchKernelGGL(opt_step_kernel<K>, dim3(ADAM_BLOCKS), dim3(256), 0, stream, p, g, s1, s2, n, \
+                                   lr, h1, h2, eps, gscale)
+    switch (kind) {
+        case 0: OPT_(0); break; case 1: OPT_(1); break; case 2: OPT_(2); break; case 3: OPT_(3); break;
+        case 4: OPT_(4); break; case 5: OPT_(5); break; case 6: OPT_(6); break; default: OPT_(7); break;
+    }
+#undef OPT_
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// total_norm_constraint's multiplier (libs/lasagne_libs/updates.py:850-853):
+// mult = clip(norm, 0, max_norm) / (eps + norm), from the device scalar asr_sqsum(want_sqrt=1) wrote.
+__global__ void norm_mult_kernel(const float* __restrict__ norm, float max_norm, float eps, float* __restrict__ mult) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float nv = norm[0];
+        const float tn = fminf(fmaxf(nv, 0.f), max_norm);
+        mult[0] = tn / (eps + nv);
+    }
+}
+extern "C" int asr_norm_clip_mult(const float* norm, float max_norm, float eps, float* mult_out, hipStream_t stream) {
+    if (!norm || !mult_out) return ASR_ERR_ARG;
+    hipLaunchKernelGGL(norm_mult_kernel, dim3(1), dim3(64), 0, stream, norm, max_norm, eps, mult_out);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

@@ -894,6 +894,31 @@ class Network(object):
                       self.scal[2:3], want_sqrt, self.adam_ws)
         return self.scal[2:3]
 
+    def opt_update(self, kind, lr, h1=0.0, h2=0.0, eps=0.0, max_grad_norm=0.0, norm_eps=1e-7, want_sqrt=True):
+        """One step of optimiser `kind` (asr_opt_step numbering) on the flat buffers; with
+        max_grad_norm > 0 the gradients are first scaled by total_norm_constraint's multiplier
+        (libs/lasagne_libs/updates.py:781-855), all on the device.  Returns the gradient norm (device
+        scalar) BEFORE scaling, which is what return_norm=True hands back."""
+        n = self.store.p.numel()
+        if not hasattr(self, 'opt_state'):
+            self.opt_state = {}
+        st = self.opt_state.get(kind)
+        if st is None:
+            st = [torch.zeros_like(self.store.p) if kind >= 1 else None,
+                  torch.zeros_like(self.store.p) if kind >= 5 else None]
+            if kind == 7:
+                st = [self.m, self.v]
+            self.opt_state[kind] = st
+        ops.sqsum(self.store.g, self.scal[2:3], True, self.adam_ws)
+        gscale = None
+        if max_grad_norm and max_grad_norm > 0:
+            ops.norm_clip_mult(self.scal[2:3], float(max_grad_norm), float(norm_eps), self.scal[4:5])
+            gscale = self.scal[4:5]
+        ops.opt_step(kind, self.store.p, self.store.g, st[0], st[1], float(lr), float(h1), float(h2), float(eps), gscale)
+        if not want_sqrt:
+            ops.sqsum(self.store.g, self.scal[2:3], False, self.adam_ws)
+        return self.scal[2:3]
+
     def grads_norm(self, want_sqrt=True):
         ops.sqsum(self.store.g, self.scal[2:3], want_sqrt, self.adam_ws)
         return self.scal[2:3]

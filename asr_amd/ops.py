@@ -135,6 +135,16 @@ def adam_step(p, g, m, v, a_t, b1, b2, eps, norm_out, want_sqrt, ws):
                                    int(want_sqrt), _p(ws), _s()), 'asr_adam_step')
 
 
+def opt_step(kind, p, g, s1, s2, lr, h1, h2, eps, gscale=None):
+    check(_lib.lib().asr_opt_step(kind, _p(p), _p(g), _p(s1) if s1 is not None else None,
+                                  _p(s2) if s2 is not None else None, p.numel(), lr, h1, h2, eps,
+                                  _p(gscale) if gscale is not None else None, _s()), 'asr_opt_step')
+
+
+def norm_clip_mult(norm, max_norm, eps, out):
+    check(_lib.lib().asr_norm_clip_mult(_p(norm), max_norm, eps, _p(out), _s()), 'asr_norm_clip_mult')
+
+
 def sqsum(g, out, want_sqrt, ws):
     check(_lib.lib().asr_sqsum(_p(g), g.numel(), _p(out), int(want_sqrt), _p(ws), _s()), 'asr_sqsum')
 

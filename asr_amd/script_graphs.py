@@ -1,0 +1,78 @@
+"""The training / prediction functions that the scripts around models/gating_hyper_nets.py build for
+themselves (scripts/dln/ted/exp_prj_lstm_dln.py:88-200; the same block is in scripts/hypernets/*.py and
+scripts/wsj/*.py): logits -> log-softmax CE, optional total_norm_constraint, `updater` chosen by name.
+
+  build_trainer(...)   -> (training_fn, train_lr, updater_params)
+      training_fn(x, mask, y, ymask) -> [frame_loss, frame_accr, train_feat_loss, network_grads_norm]
+  build_predictor(...) -> predict_fn(x, mask, y, ymask) -> [frame_prd_idx, frame_loss]
+  eval_network(predict_fn, data_stream) -> (nll, fer)                                   (:186-215)
+
+Symbolic arguments are placeholders, as in asr_amd.comp_graph_utils.  Not on the HIP path yet and
+refused loudly: the sample-feature variance regulariser (`feat_reg != 0`, :120-127) and L2 weight decay
+(`weight_decay > 0`, :129-131)."""
+import numpy as np
+import torch
+
+from .comp_graph_utils import _dev, _reducer
+from .updates import SharedScalar, total_norm_constraint
+
+
+def build_trainer(input_data, input_mask, target_data, target_mask, network_params, network_reg_params,
+                  output_layer, cond_layer_list, feat_reg, weight_decay, updater, learning_rate,
+                  max_grad_norm=0.0, load_updater_params=None):
+    network = output_layer
+    if feat_reg and cond_layer_list:
+        raise NotImplementedError('asr_amd: feat_reg != 0 (sample-feature variance term) is not implemented')
+    if weight_decay and weight_decay > 0:
+        raise NotImplementedError('asr_amd: weight_decay > 0 (L2 penalty) is not implemented')
+    grads = None
+    if max_grad_norm and max_grad_norm > 0.:
+        grads, _ = total_norm_constraint(tensor_vars=None, max_norm=max_grad_norm, return_norm=True)
+    train_lr = SharedScalar(learning_rate, 'train_lr')
+    update, updater_params = updater(loss_or_grads=grads, params=network_params, learning_rate=train_lr,
+                                     load_params_dict=load_updater_params)
+    red = _reducer(network)
+    f32 = torch.float32
+
+    def training_fn(x, mask, y, ymask):
+        ym = _dev(network, ymask, f32)
+        ce, ok, _ = network.loss(_dev(network, x, f32), _dev(network, mask, f32), _dev(network, y, torch.int32),
+                                 ym, cond=None, train=True)
+        network.backward()
+        red.finish()
+        gn = update.apply(network, want_sqrt=True)
+        out = torch.cat([ce, ok, gn, ym.sum().reshape(1)]).cpu().numpy()
+        network.check_status()
+        nfr = max(float(out[3]), 1.0)
+        return [np.float32(out[0] / nfr), np.float32(out[1] / nfr), np.float32(0.0), np.float32(out[2])]
+
+    return training_fn, train_lr, updater_params
+
+
+def build_predictor(input_data, input_mask, target_data, target_mask, output_layer):
+    network = output_layer
+    f32 = torch.float32
+
+    def predict_fn(x, mask, y, ymask):
+        ym = _dev(network, ymask, f32)
+        ce, ok, pred = network.loss(_dev(network, x, f32), _dev(network, mask, f32),
+                                    _dev(network, y, torch.int32), ym, cond=None, train=False)
+        out = torch.cat([ce, ym.sum().reshape(1)]).cpu().numpy()
+        network.check_status()
+        return [pred.cpu().numpy(), np.float32(out[0] / max(float(out[1]), 1.0))]
+
+    return predict_fn
+
+
+def eval_network(predict_fn, data_stream):
+    """scripts/dln/ted/exp_prj_lstm_dln.py:186-215: batch-averaged NLL and frame error rate."""
+    total_nll = 0.; total_fer = 0.; cnt = 0
+    for cnt, data in enumerate(data_stream.get_epoch_iterator(), start=1):
+        x = np.asarray(data[0], np.float32); m = np.asarray(data[1], np.float32)
+        y = np.asarray(data[2]); ym = np.asarray(data[3], np.float32)
+        pred, nll = predict_fn(x, m, y, ym)
+        match = (np.asarray(pred).reshape(y.shape) == y) * ym
+        total_nll += float(nll)
+        total_fer += 1.0 - float(match.sum() / ym.sum())
+    cnt = max(cnt, 1)
+    return total_nll / cnt, total_fer / cnt

@@ -97,6 +97,17 @@ int asr_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
                   float eps, float* grads_norm_out, int want_sqrt, float* ws, asr_stream_t stream);
 int asr_sqsum(const float* g, size_t n, float* out, int want_sqrt, float* ws, asr_stream_t stream);
 
+/* The other optimisers of libs/lasagne_libs/updates.py as one elementwise pass: kind 0 sgd (:64-92),
+ * 1 momentum (:95-149,152-188), 2 nesterov_momentum (:191-295), 3 adagrad (:298-363), 4 rmsprop
+ * (:366-433), 5 adadelta (:436-531), 6 adamax (:621-698; lr = a_t = lr/(1-b1^t)), 7 adam (:534-618;
+ * lr = a_t).  s1/s2: the optimiser's state tensors (velocity | accu | m, delta_accu | u | v), h1/h2:
+ * momentum | rho | beta1, beta2.  gscale: NULL or a device scalar every gradient is multiplied by first
+ * (the multiplier of total_norm_constraint, :781-855, written by asr_norm_clip_mult). */
+int asr_opt_step(int kind, float* p, const float* g, float* s1, float* s2, size_t n, float lr, float h1,
+                 float h2, float eps, const float* gscale, asr_stream_t stream);
+/* mult_out[0] = clip(norm[0], 0, max_norm) / (eps + norm[0])   (libs/lasagne_libs/updates.py:850-853) */
+int asr_norm_clip_mult(const float* norm, float max_norm, float eps, float* mult_out, asr_stream_t stream);
+
 /* K2 (LSTM family).  Persistent recurrent scan, forward and BPTT: theano.scan(step_masked) and its
  * gradient for libs/lhuclstm_layers.py:73-130,205-211; libs/lasagne_libs/recurrent_layers.py:437-521,
  * :707-789, :1237-1310. */

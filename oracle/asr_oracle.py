@@ -836,6 +836,49 @@ def adam_step(params, grads, m, v, t_prev, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     return t
 
 
+def opt_step(kind, params, grads, s1, s2, lr, h1=0.0, h2=0.0, eps=0.0, t_prev=0):
+    """The other updaters of libs/lasagne_libs/updates.py, in-place on lists of arrays; returns t.
+    kind: 'sgd' :87-90, 'momentum' :143-147, 'nesterov' :244-249, 'adagrad' :357-361, 'rmsprop' :427-431,
+    'adadelta' :515-529, 'adamax' :662-664,687-696."""
+    t = t_prev + 1
+    for i, (p_, g_) in enumerate(zip(params, grads)):
+        if kind == 'sgd':
+            p_[...] = p_ - lr * g_
+        elif kind == 'momentum':
+            x = h1 * s1[i] + (p_ - lr * g_) - p_
+            s1[i][...] = x; p_[...] = p_ + x
+        elif kind == 'nesterov':
+            upd = p_ - lr * g_
+            x = h1 * s1[i] + upd - p_
+            s1[i][...] = x; p_[...] = h1 * x + upd
+        elif kind == 'adagrad':
+            s1[i][...] = s1[i] + g_ ** 2
+            p_[...] = p_ - lr * g_ / np.sqrt(s1[i] + eps)
+        elif kind == 'rmsprop':
+            s1[i][...] = h1 * s1[i] + (1 - h1) * g_ ** 2
+            p_[...] = p_ - lr * g_ / np.sqrt(s1[i] + eps)
+        elif kind == 'adadelta':
+            s1[i][...] = h1 * s1[i] + (1 - h1) * g_ ** 2
+            u = g_ * np.sqrt(s2[i] + eps) / np.sqrt(s1[i] + eps)
+            p_[...] = p_ - lr * u
+            s2[i][...] = h1 * s2[i] + (1 - h1) * u ** 2
+        elif kind == 'adamax':
+            a_t = lr / (1 - h1 ** t)
+            s1[i][...] = h1 * s1[i] + (1 - h1) * g_
+            s2[i][...] = np.maximum(h2 * s2[i], np.abs(g_))
+            p_[...] = p_ - a_t * s1[i] / (s2[i] + eps)
+        else:
+            raise KeyError(kind)
+    return t
+
+
+def total_norm_constraint(grads, max_norm, epsilon=1e-7):
+    """libs/lasagne_libs/updates.py:848-855 -> (scaled grads, norm)."""
+    norm = np.sqrt(sum(np.sum(g ** 2) for g in grads))
+    mult = np.clip(norm, 0, max_norm) / (epsilon + norm)
+    return [g * mult for g in grads], norm
+
+
 def gen_win(batch, win_size, right_context=0):
     """libs/utils.py:178-191."""
     n_seq = batch[0].shape[1]

@@ -1,0 +1,84 @@
+"""GPU parity of asr_opt_step / asr_norm_clip_mult (the updaters of libs/lasagne_libs/updates.py other
+than Adam, and total_norm_constraint) against the oracle's float64 restatement, through the C-ABI and
+through the host mirror (asr_amd.updates, asr_amd.script_graphs)."""
+import numpy as np
+import pytest
+import torch
+
+from common import make_batch
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KINDS = [('sgd', 0, dict(lr=0.05)), ('momentum', 1, dict(lr=0.05, h1=0.9)), ('nesterov', 2, dict(lr=0.05, h1=0.9)),
+         ('adagrad', 3, dict(lr=0.5, eps=1e-6)), ('rmsprop', 4, dict(lr=0.1, h1=0.9, eps=1e-6)),
+         ('adadelta', 5, dict(lr=1.0, h1=0.95, eps=1e-6)), ('adamax', 6, dict(lr=0.002, h1=0.9, h2=0.999, eps=1e-8))]
+
+
+@pytest.mark.parametrize('name,kind,hp', KINDS)
+@pytest.mark.parametrize('clip', [0.0, 0.7])
+def test_opt_step_kernel(name, kind, hp, clip):
+    from asr_amd import ops
+    rng = np.random.default_rng(3 + kind)
+    n = 4099                                   # not a multiple of 4: exercises the tail
+    p0 = rng.standard_normal(n); s1 = np.zeros(n); s2 = np.zeros(n)
+    dev = 'cuda:0'
+    P = torch.from_numpy(p0.astype(np.float32)).to(dev)
+    S1 = torch.zeros(n, device=dev); S2 = torch.zeros(n, device=dev)
+    ws = torch.zeros(1024, device=dev); scal = torch.zeros(8, device=dev)
+    po = [p0.copy()]; so1 = [s1]; so2 = [s2]
+    t = 0
+    for it in range(4):
+        g = rng.standard_normal(n) * (0.5 + it)
+        G = torch.from_numpy(g.astype(np.float32)).to(dev)
+        gs = None
+        gg = [G.cpu().numpy().astype(np.float64)]
+        if clip:
+            ops.sqsum(G, scal[2:3], True, ws)
+            ops.norm_clip_mult(scal[2:3], clip, 1e-7, scal[4:5])
+            gs = scal[4:5]
+            gg, norm = O.total_norm_constraint(gg, clip)
+            assert abs(scal[2].item() - norm) / norm < 1e-5
+        lr = hp['lr']
+        if name == 'adamax':
+            ops.opt_step(kind, P, G, S1, S2, lr / (1 - hp['h1'] ** (t + 1)), hp['h1'], hp['h2'], hp['eps'], gs)
+        else:
+            ops.opt_step(kind, P, G, S1 if kind >= 1 else None, S2 if kind >= 5 else None, lr, hp.get('h1', 0.0),
+                         hp.get('h2', 0.0), hp.get('eps', 0.0), gs)
+        t = O.opt_step(name, po, gg, so1, so2, lr, hp.get('h1', 0.0), hp.get('h2', 0.0), hp.get('eps', 0.0), t_prev=t)
+    err = np.max(np.abs(P.cpu().numpy() - po[0])) / np.max(np.abs(po[0]))
+    assert err < 1e-5, err
+
+
+def test_script_trainer_momentum_clipped():
+    """build_trainer of scripts/dln/ted/exp_prj_lstm_dln.py:88-165 with updater=momentum and
+    max_grad_norm: 3 steps against the oracle (loss, accuracy, grads norm, parameters)."""
+    from asr_amd.gating_hyper_nets import deep_projection_lstm_model
+    from asr_amd.script_graphs import build_trainer, build_predictor
+    from asr_amd.updates import momentum
+    net = deep_projection_lstm_model(None, None, 5, 6, 2, 4, 8, grad_clipping=1.0, dropout=0.0, device='cuda:0', seed=31)
+    b = make_batch(np.random.default_rng(32), 3, 7, 5, 6)
+    params = net.get_all_params(trainable=True)
+    fn, lr, upd = build_trainer(None, None, None, None, params, params, net, [], 0.0, 0.0, momentum, 0.05,
+                                max_grad_norm=0.3)
+    vals = [v.astype(np.float64) for v in net.get_all_param_values()]
+    vel = [np.zeros_like(v) for v in vals]
+    desc = net.describe()
+    for it in range(3):
+        onet = O.OracleNetwork(desc, vals)
+        ce, ces, opred, og = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], None)
+        og, norm = O.total_norm_constraint(og, 0.3)
+        fl, acc, fr, gn = fn(b['x'], b['mask'], b['y'], b['mask'])
+        nfr = b['mask'].sum()
+        assert abs(fl - ces / nfr) / (ces / nfr) < 2e-5
+        assert abs(acc - ((opred == b['y']) * b['mask']).sum() / nfr) < 1e-6
+        assert abs(gn - norm) / norm < 1e-4
+        O.opt_step('momentum', vals, og, vel, None, 0.05, 0.9)
+        for a, o in zip(net.get_all_param_values(), vals):
+            assert np.max(np.abs(a - o)) < 2e-5 * max(1.0, np.max(np.abs(o)))
+    pf = build_predictor(None, None, None, None, net)
+    pred, fl = pf(b['x'], b['mask'], b['y'], b['mask'])
+    onet = O.OracleNetwork(desc, vals)
+    ce, ces, opred, _ = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], None)
+    assert abs(fl - ces / b['mask'].sum()) / (ces / b['mask'].sum()) < 2e-5
+    assert ((pred.reshape(opred.shape) == opred) | (b['mask'] == 0)).all()

@@ -310,3 +310,37 @@ def test_gloo_world2_bucketed_allreduce(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert 'rank %d ok' % r in o
+
+
+def test_oracle_updaters_known_answers():
+    """Hand-computed steps of libs/lasagne_libs/updates.py formulas (momentum :143-147, nesterov
+    :244-249, adamax :662-696, total_norm_constraint :848-855)."""
+    from oracle import asr_oracle as O
+    p = [np.array([1.0, -2.0])]; g = [np.array([0.5, 0.25])]; v = [np.zeros(2)]
+    O.opt_step('momentum', p, g, v, None, 0.1, 0.9)
+    assert np.allclose(v[0], [-0.05, -0.025]) and np.allclose(p[0], [0.95, -2.025])
+    O.opt_step('momentum', p, g, v, None, 0.1, 0.9)
+    assert np.allclose(v[0], [-0.095, -0.0475]) and np.allclose(p[0], [0.855, -2.0725])
+    p = [np.array([1.0])]; v = [np.zeros(1)]
+    O.opt_step('nesterov', p, [np.array([1.0])], v, None, 0.1, 0.9)
+    assert np.allclose(v[0], [-0.1]) and np.allclose(p[0], [1.0 - 0.09 - 0.1])
+    p = [np.array([1.0])]; m = [np.zeros(1)]; u = [np.zeros(1)]
+    t = O.opt_step('adamax', p, [np.array([2.0])], m, u, 0.002, 0.9, 0.999, 1e-8, t_prev=0)
+    assert t == 1 and np.allclose(m[0], [0.2]) and np.allclose(u[0], [2.0])
+    assert np.allclose(p[0], [1.0 - (0.002 / 0.1) * 0.2 / (2.0 + 1e-8)])
+    sg, norm = O.total_norm_constraint([np.array([3.0]), np.array([4.0])], 1.0)
+    assert abs(norm - 5.0) < 1e-12 and np.allclose(np.concatenate(sg), [0.6, 0.8], atol=1e-6)
+    sg, norm = O.total_norm_constraint([np.array([0.3]), np.array([0.4])], 1.0)
+    assert np.allclose(np.concatenate(sg), [0.3, 0.4], atol=1e-6)
+
+
+def test_updates_api_shapes():
+    from asr_amd import updates as U
+    for f in (U.sgd, U.momentum, U.nesterov_momentum, U.adagrad, U.rmsprop, U.adadelta, U.adamax, U.adam):
+        upd, d = f(loss_or_grads=None, params=[], learning_rate=0.1)
+        assert hasattr(upd, 'apply')
+    upd, d = U.adamax(None, [], 0.002, load_params_dict={'t_prev': np.float32(7)})
+    assert float(d['t_prev'].get_value()) == 7.0
+    cg, nh = U.total_norm_constraint(None, max_norm=5.0, return_norm=True)
+    upd, d = U.adam(loss_or_grads=cg, params=[], learning_rate=0.1)
+    assert upd.kind == 7 and upd.clip.max_norm == 5.0
