@@ -344,3 +344,35 @@ def test_updates_api_shapes():
     cg, nh = U.total_norm_constraint(None, max_norm=5.0, return_norm=True)
     upd, d = U.adam(loss_or_grads=cg, params=[], learning_rate=0.1)
     assert upd.kind == 7 and upd.clip.max_norm == 5.0
+
+
+def test_transformers():
+    """data/transformers.py:15-63,133-177; libs/utils.py:208-262; bin/forward_lstm2.py:99-101."""
+    from asr_amd import transformers as TR
+
+    class S(object):
+        def __init__(self, batches): self.b = batches
+        def get_epoch_iterator(self): return iter(self.b)
+
+    f = [np.arange(6, dtype=np.float32).reshape(3, 2), np.arange(4, dtype=np.float32).reshape(2, 2)]
+    iv = [np.ones((3, 1), np.float32), 2 * np.ones((2, 1), np.float32)]
+    tg = [np.array([1, 2, 3], np.int32), np.array([4, 5], np.int32)]
+    out = next(iter(TR.DelayTransformer(S([(f, iv, tg)]), 2).get_epoch_iterator()))
+    assert out[0][0].shape == (5, 2) and (out[0][0][3:] == f[0][-1]).all()
+    assert out[1][1].shape == (4, 1) and (out[1][1] == 2).all()
+    assert out[2][0].tolist() == [0, 0, 1, 2, 3] and out[2][1].tolist() == [0, 0, 4, 5]
+    # length sort: batches of 1 example each, cache 4 -> sorted runs of 4, then the rest
+    lens = [5, 2, 9, 3, 7, 1]
+    st = S([([np.zeros((n, 1))],) for n in lens])
+    got = [len(b[0][0]) for b in TR.LengthSortTransformer(st, 2, 4).get_epoch_iterator() for _ in [0]]
+    allg = [len(x) for b in TR.LengthSortTransformer(st, 2, 4).get_epoch_iterator() for x in b[0]]
+    assert sorted(allg) == sorted(lens) and allg[:4] == [2, 3, 5, 9]
+    with pytest.raises(ValueError):
+        TR.LengthSortTransformer(st, 4, 2)
+    sk = TR.skip_frames([[np.arange(7)], [np.arange(14).reshape(7, 2)]], 3)
+    assert sk[0][0].tolist() == [0, 3, 6] and sk[1][0].shape == (3, 2)
+    fx = list(TR.skip_frames_fixed([[np.arange(7)]], 2, return_first=True))
+    assert fx[0][0][0].tolist() == [0, 2, 4, 6]
+    assert list(TR.skip_frames_fixed([[np.arange(3)]], 1))[0][0][0].tolist() == [0, 1, 2]
+    o = TR.unskip(np.arange(6, dtype=np.float32).reshape(1, 3, 2), 3, 7)
+    assert o.shape == (1, 7, 2) and (o[0, 3] == o[0, 5]).all() and (o[0, 6] == [4, 5]).all()
