@@ -51,40 +51,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // staging registers: each thread moves 8 A and 8 B elements per K-tile
-    float ra[8], rb[8];
-    auto load_tiles = [&](int k0) {
-        // A tile: BM x BK.  Thread mapping chosen so that global reads are contiguous for the
-        // stored layout: !TA -> consecutive threads along k (row contiguous); TA -> along m.
+    // staging registers: each thread moves 2 x 4 A and 2 x 4 B elements per K-tile, as ONE 16-byte global
+    // load per group of 4 along the operand's contiguous dimension whenever the group is in range and
+    // 16-byte aligned (wave-uniform test of base pointer and leading dimension), element-wise otherwise
+    f32x4 ra[2], rb[2];
+    const bool vecA = ((((uintptr_t)A) & 15) == 0) && ((lda & 3) == 0);
+    const bool vecB = ((((uintptr_t)B) & 15) == 0) && ((ldb & 3) == 0);
+    // X stored [R][C] row-major (C contiguous); group of 4 along C starting at (r, c)
+    auto ld4 = [&](const float* X, int ld, int r, int c, int R, int C, bool vec) -> f32x4 {
+        if (vec && r < R && c + 3 < C) return *(const f32x4*)(X + (size_t)r * ld + c);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int idx = e * 256 + tid;
-            int mm, kk;
-            if (TA) { mm = idx % BM; kk = idx / BM; } else { kk = idx % BK; mm = idx / BK; }
-            ra[e] = ldg_op<TA>(A, lda, m0 + mm, k0 + kk, M, K);
+            for (int i = 0; i < 4; ++i) if (c + i < C) v[i] = X[(size_t)r * ld + c + i];
         }
+        return v;
+    };
+    auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int idx = e * 256 + tid;
-            int nn, kk;
-            if (TB) { kk = idx % BK; nn = idx / BK; } else { nn = idx % BN; kk = idx / BN; }
-            rb[e] = ldg_op<TB>(B, ldb, k0 + kk, n0 + nn, K, N);
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 256 + tid;
+            if (TA) ra[e] = ld4(A, lda, k0 + idx / 32, m0 + (idx % 32) * 4, K, M, vecA);     // stored [K][M]
+            else    ra[e] = ld4(A, lda, m0 + idx / 4, k0 + (idx % 4) * 4, M, K, vecA);       // stored [M][K]
+            if (TB) rb[e] = ld4(B, ldb, n0 + idx / 4, k0 + (idx % 4) * 4, N, K, vecB);       // stored [N][K]
+            else    rb[e] = ld4(B, ldb, k0 + idx / 32, n0 + (idx % 32) * 4, K, N, vecB);     // stored [K][N]
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int idx = e * 256 + tid;
-            int mm, kk;
-            if (TA) { mm = idx % BM; kk = idx / BM; } else { kk = idx % BK; mm = idx / BK; }
-            As[buf][kk][mm] = ra[e];
-        }
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 256 + tid;
+            if (TA) *(f32x4*)&As[buf][idx / 32][(idx % 32) * 4] = ra[e];
+            else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int idx = e * 256 + tid;
-            int nn, kk;
-            if (TB) { kk = idx % BK; nn = idx / BK; } else { nn = idx % BN; kk = idx / BN; }
-            Bs[buf][kk][nn] = rb[e];
+                for (int i = 0; i < 4; ++i) As[buf][(idx % 4) * 4 + i][idx / 4] = ra[e][i];
+            }
+            if (TB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[buf][(idx % 4) * 4 + i][idx / 4] = rb[e][i];
+            } else *(f32x4*)&Bs[buf][idx / 32][(idx % 32) * 4] = rb[e];
         }
     };
 
