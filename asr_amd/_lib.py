@@ -31,7 +31,8 @@ class HyperDir(C.Structure):
     _fields_ = [('reverse', i32), ('xproj', fp), ('xhproj', fp), ('wpack', fp),
                 ('cvec', fp), ('r_out', fp), ('ld_r', i32), ('hh_out', fp),
                 ('gates', fp), ('cst', fp), ('hgates', fp), ('hcst', fp), ('aD', fp),
-                ('dr_ext', fp), ('ld_dr', i32), ('dXp', fp), ('dXh', fp), ('dA', fp), ('dD', fp)]
+                ('dr_ext', fp), ('ld_dr', i32), ('dXp', fp), ('dXh', fp), ('dA', fp), ('dD', fp),
+                ('dcv', fp), ('dbh', fp)]
 
 
 class HyperScanDesc(C.Structure):

@@ -32,6 +32,8 @@ struct HyperDir {
     float* dXh;              // (T,B,4H) clipped hyper gate grads -> dW_xhat, dbhat, dW_hhat, dx
     float* dA;               // (T,B,4N) dgates * d_h           -> dW_h
     float* dD;               // (T,B,3,4N) [dgates*a, dgates*xproj, dgates] -> dM, dcvec
+    float* dcv;              // (ceil(B/8),12N) or null: column sums of dD over time and batch, per batch chunk
+    float* dbh;              // (ceil(B/8),4H)  or null: column sums of dXh
 };
 
 struct HyperArgs {
@@ -502,6 +504,8 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     const bool hvalid = (q < UH) && (hu < H);
     float dc = 0.f, dh_pass = 0.f, dh_in = 0.f;         // wave 0 lanes
     float dhc = 0.f, dhh_pass = 0.f, dhh_rec = 0.f;     // wave 1 lanes
+    // running column sums (d cvec, d bhat): formed here for free instead of re-reading dD / dXh
+    f32x4 cs_h = {0, 0, 0, 0}, cs_x = {0, 0, 0, 0}, cs_g = {0, 0, 0, 0}, cs_hg = {0, 0, 0, 0};
     __syncthreads();
 
     // saved tensors of the step about to be processed, prefetched one step ahead
@@ -600,6 +604,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             }
             da4 = dg4 * dh4;
             dd_h = dg4 * a4; dd_x = dg4 * x4;
+            cs_h += dd_h; cs_x += dd_x; cs_g += dg4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dal[(q * 4 + k) * 16 + bl] = da4[k];
@@ -699,6 +704,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             } else {
                 dhh_pass = dhh_t;
             }
+            cs_hg += dhg;
             // all-gather payload: dgx[par][hu][b][gate], one 16-byte write-through store
             st_sc1_f4(dgx_rs, (unsigned)((((size_t)par * H + hu) * 16 + bl) * 16), dhg);
         }
@@ -800,6 +806,27 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         c0 = c1; c1 = n_c2; hc0 = hc1; hc1 = n_hc2;
         STAMP(8);
         __syncthreads();
+    }
+    if (D.dcv && wave == 0) {                           // sum over the 16 batch lanes, lane bl == 0 writes
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cs_h[e] += __shfl_xor(cs_h[e], o); cs_x[e] += __shfl_xor(cs_x[e], o); cs_g[e] += __shfl_xor(cs_g[e], o);
+            }
+        }
+        if (bl == 0) {
+            float* o_ = D.dcv + (size_t)chunk * 12 * N;
+            *(f32x4*)(o_ + col4) = cs_h; *(f32x4*)(o_ + 4 * N + col4) = cs_x; *(f32x4*)(o_ + 8 * N + col4) = cs_g;
+        }
+    }
+    if (D.dbh && wave == 1) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs_hg[e] += __shfl_xor(cs_hg[e], o);
+        }
+        if (bl == 0 && hvalid) *(f32x4*)(D.dbh + (size_t)chunk * 4 * H + hu * 4) = cs_hg;
     }
     STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }

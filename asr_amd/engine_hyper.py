@@ -143,6 +143,9 @@ class HyperPair(object):
             c['dXh'] = self._buf('dXh%d' % d, rows, 4 * H); Dd.dXh = c['dXh'].data_ptr()
             c['dA'] = self._buf('dA%d' % d, rows, 4 * N); Dd.dA = c['dA'].data_ptr()
             c['dD'] = self._buf('dD%d' % d, rows, 12 * N); Dd.dD = c['dD'].data_ptr()
+            nsl = (B + 7) // 8                         # per batch chunk; unused slots stay zero
+            c['dcv'] = self._buf('dcv%d' % d, nsl, 12 * N); c['dcv'].zero_(); Dd.dcv = c['dcv'].data_ptr()
+            c['dbh'] = self._buf('dbh%d' % d, nsl, 4 * H); c['dbh'].zero_(); Dd.dbh = c['dbh'].data_ptr()
         net.scan_hyper(self, desc, backward=True)
         # critical path first: dX feeds the BPTT scan of the layer below
         dX = self._buf('dX', rows, self.D) if need_dx else None
@@ -174,11 +177,11 @@ class HyperPair(object):
             gWxh = dp.g('Wxh')
             ops.gemm(R[sl_prev], dXh[sl_cur], gWxh[:N], ta=True)              # dW_xhat (h rows)
             ops.gemm(X, dXh, gWxh[N:], ta=True)                               # dW_xhat (x rows)
-            ops.colreduce(dXh, dp.g('bh'), rows, 4 * H)
+            ops.colreduce(c['dbh'], dp.g('bh'), c['dbh'].shape[0], 4 * H)     # summed over time in the scan
             ops.gemm(Hh[sl_prev], dXh[sl_cur], dp.g('Whh'), ta=True)          # dW_hhat
             dMi = self._buf('dMi%d' % d, H + 1, 12 * N)
             ops.gemm(Hh, dD, dMi[:H], ta=True)
-            ops.colreduce(dD, dMi[H], rows, 12 * N)
+            ops.colreduce(c['dcv'], dMi[H], c['dcv'].shape[0], 12 * N)
             dMg = self._buf('dMg%d' % d, H + 1, 12 * N)
             perm4(dMi, dMg, (H + 1) * 3, N, inverse=True)
             dMg = dMg.view(H + 1, 3, 4, N)

@@ -145,6 +145,9 @@ class ScalingPair(object):
             c['dXh'] = self._buf('dXh%d' % d, rows, 4 * H); Dd.dXh = c['dXh'].data_ptr()
             c['dA'] = self._buf('dA%d' % d, rows, 4 * N); Dd.dA = c['dA'].data_ptr()
             c['dD'] = self._buf('dD%d' % d, rows, 12 * N); Dd.dD = c['dD'].data_ptr()
+            nsl = (B + 7) // 8                         # per batch chunk; unused slots stay zero
+            c['dcv'] = self._buf('dcv%d' % d, nsl, 12 * N); c['dcv'].zero_(); Dd.dcv = c['dcv'].data_ptr()
+            c['dbh'] = self._buf('dbh%d' % d, nsl, 4 * H); c['dbh'].zero_(); Dd.dbh = c['dbh'].data_ptr()
         net.scan_hyper(self, desc, backward=True)
         dX = self._buf('dX', rows, self.D) if need_dx else None
         if need_dx:                                   # critical path: feeds the scan of the layer below
@@ -173,8 +176,8 @@ class ScalingPair(object):
             gWxh = dp.g('Wxh')
             ops.gemm(R[sl_prev], dXh[sl_cur], gWxh[:N], ta=True)
             ops.gemm(X, dXh, gWxh[N:], ta=True)
-            ops.colreduce(dXh, dp.g('bh'), rows, 4 * H)
+            ops.colreduce(c['dbh'], dp.g('bh'), c['dbh'].shape[0], 4 * H)     # summed over time in the scan
             ops.gemm(Hh[sl_prev], dXh[sl_cur], dp.g('Whh'), ta=True)
             gM = dp.g('M')
             ops.gemm(Hh, dD, gM[:H], ta=True)
-            ops.colreduce(dD, gM[H], rows, 12 * N)
+            ops.colreduce(c['dcv'], gM[H], c['dcv'].shape[0], 12 * N)

@@ -180,6 +180,8 @@ typedef struct asr_hyper_dir {
     float* dXh;               /* (T,B,4H) hyper gate grads -> dW_xhat, dbhat, dW_hhat, dx */
     float* dA;                /* (T,B,4N) dgates*d_h  -> dW_h */
     float* dD;                /* (T,B,3,4N) [dgates*a, dgates*xproj, dgates] -> dM, dcvec */
+    float* dcv;               /* (ceil(B/8),12N) or NULL: column sums of dD (d cvec) per 16-row batch chunk */
+    float* dbh;               /* (ceil(B/8),4H) or NULL: column sums of dXh (d bhat) per batch chunk */
 } asr_hyper_dir;
 
 typedef struct asr_hyper_scan_desc {
