@@ -37,7 +37,7 @@ class HyperDir(C.Structure):
 
 class HyperScanDesc(C.Structure):
     _fields_ = [('T', i32), ('B', i32), ('N', i32), ('H', i32), ('ndir', i32), ('grad_clip', f32),
-                ('clip_outcell', i32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
+                ('clip_outcell', i32), ('lhuc_reparam', i32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
                 ('dir', HyperDir * 2)]
 
 

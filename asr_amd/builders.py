@@ -90,6 +90,29 @@ def build_deep_hyperlstm(layer_name, input_var, mask_var, input_dim, num_layers,
     return net.finalize(seed)
 
 
+def build_deep_hyperlhuclstm(layer_name, input_var, mask_var, input_dim, num_layers, num_units,
+                             num_hyper_units, num_proj_units, output_dim, grad_clipping, is_bidir, ivector_dim,
+                             ivector_var=None, reparam='relu', device=None, seed=0):
+    """The wiring of build_deep_hyperlstm (libs/deep_hyperlstm_builder.py:8-37) with
+    HyperLHUCLSTMLayer (libs/lasagne_libs/hyper_lhuc_layers.py:509-678) as the layer class.  The
+    reference defines the class but none of its builders instantiates it (its `layer_name` argument is
+    ignored, :20-27); this builder exists so that the class is reachable the same way."""
+    from .engine_hyper import HyperLHUCPair
+    net = _new(device, seed)
+    D = input_dim
+    if ivector_var is not None and ivector_var is not False:
+        net.ivector_concat = True; net.uses_cond = True
+        D += ivector_dim
+    ndir = 2 if is_bidir else 1
+    for li in range(num_layers):
+        pair = HyperLHUCPair(net, len(net.pairs), D, num_units, num_hyper_units, num_proj_units,
+                             grad_clipping, ndir, reparam=reparam)
+        net.add_pair(pair, [specs.hyperlhuc_params(D, num_units, num_hyper_units, num_proj_units)] * ndir)
+        D = pair.out_dim
+    net.set_output(D, output_dim, 'softmax')
+    return net.finalize(seed)
+
+
 def _build_lhuc_ivector(input_dim, num_layers, num_units, num_proj_units, output_dim, num_pred_layers,
                         num_pred_units, batch_size, grad_clipping, is_bidir, use_layer_norm,
                         use_ivector_input, ivector_dim, stateful, device, seed):

@@ -42,6 +42,7 @@ struct HyperArgs {
     int ndir, chunk0, rpc;       // rpc = batch rows per chunk/group (8 or 16)
     float clip;
     float clip_out;              // bound of the extra grad_clip on outcell (ScalingHyperLSTMLayer), 0 = none
+    int lhuc;                    // HyperLHUCLSTMLayer: 0 off, else 1 + reparam (relu, exp, identity, 2sigmoid)
     const float* mask; int msb, mst;
     HyperDir d[2];
     unsigned* sync;
@@ -181,6 +182,18 @@ extern "C" int asr_hyper_pack_w(const float* Wh, const float* Whx, const float* 
                        hyper_pack_floats_wg(A, mode), out);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
+}
+
+// reparam_* of libs/lasagne_libs/hyper_lhuc_layers.py:17-27 and their derivatives (kind = HyperArgs.lhuc)
+__device__ __forceinline__ float lhuc_rp(int kind, float v) {
+    return kind == 1 ? fmaxf(v, 0.f) : kind == 2 ? expf(v) : kind == 3 ? v : 2.f * sigmoidf_(v);
+}
+__device__ __forceinline__ float lhuc_drp(int kind, float v) {
+    if (kind == 1) return v > 0.f ? 1.f : 0.f;
+    if (kind == 2) return expf(v);
+    if (kind == 3) return 1.f;
+    const float sg = sigmoidf_(v);
+    return 2.f * sg * (1.f - sg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,10 +429,13 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
                 dx4 += *(const f32x4*)(red + ((size_t)(1 * 4 + w) * 64 + lane) * 4);
                 bb4 += *(const f32x4*)(red + ((size_t)(2 * 4 + w) * 64 + lane) * 4);
             }
-            const f32x4 pre = a4 * dh4 + (x4 * dx4 + bb4);       // :393-395
+            // HyperLHUC: M carries d_h = d_x = 1 and, in gate column 0 of the bias tile, the LHUC
+            // pre-scale d = (hhat.W_hhat_h + b).W_hz of the unit; the gates are the plain h.W_h + xproj
+            const f32x4 pre = A.lhuc ? a4 * dh4 + x4 * dx4 : a4 * dh4 + (x4 * dx4 + bb4);       // :393-395 | :593
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
             const float c_new = fg * c + ig * gg;
-            const float r_new = og * tanhf_(c_new);
+            float r_new = og * tanhf_(c_new);
+            if (A.lhuc) r_new *= lhuc_rp(A.lhuc, bb4[0]);        // hyper_lhuc_layers.py:612
             if (m != 0.f) { c = c_new; r = r_new; }
             {
                 const float r1 = __shfl(r, bl + 16), r2 = __shfl(r, bl + 32), r3 = __shfl(r, bl + 48);
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
                 *(f32x4*)(D.gates + row * 4 * N + col4) = gsave;
                 float* ad_ = D.aD + row * 12 * N;
                 *(f32x4*)(ad_ + col4) = a4;
-                *(f32x4*)(ad_ + 4 * N + col4) = dh4;
+                *(f32x4*)(ad_ + 4 * N + col4) = A.lhuc ? bb4 : dh4;   // LHUC: d_h == 1, keep the pre-scale
                 *(f32x4*)(ad_ + 8 * N + col4) = dx4;
             }
         }
@@ -585,14 +601,20 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         STAMP(9);
 
         // ---- S1: main cell backward (wave 0)
-        f32x4 dg4 = {0, 0, 0, 0}, da4 = {0, 0, 0, 0}, dd_h = {0, 0, 0, 0}, dd_x = {0, 0, 0, 0};
+        f32x4 dg4 = {0, 0, 0, 0}, da4 = {0, 0, 0, 0}, dd_h = {0, 0, 0, 0}, dd_x = {0, 0, 0, 0}, dd_b = {0, 0, 0, 0};
         if (wave == 0) {
             const float dh_t = dre + dh_pass + dh_in;       // dh_in: recurrent terms formed last step
+            // HyperLHUC: h = r0 * reparam(d); slot 1 of aD holds d (gate column 0), d_h == 1
+            float sc = 1.f, dsc = 0.f, ds_pre = 0.f;
+            f32x4 dh4e = dh4;
+            if (A.lhuc) { sc = lhuc_rp(A.lhuc, dh4[0]); dsc = lhuc_drp(A.lhuc, dh4[0]); dh4e = f32x4{1.f, 1.f, 1.f, 1.f}; }
             if (on) {
                 const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
                 const float tc = tanhf_(c_new);
-                const float do_ = dh_t * tc;
-                const float dct = dc + clipf_(dh_t * og * (1.f - tc * tc), A.clip_out);
+                const float dr0 = dh_t * sc;
+                ds_pre = dh_t * (og * tc) * dsc;
+                const float do_ = dr0 * tc;
+                const float dct = dc + clipf_(dr0 * og * (1.f - tc * tc), A.clip_out);
                 dg4[0] = clipf_(dct * gg * ig * (1.f - ig), A.clip);
                 dg4[1] = clipf_(dct * c_prev * fg * (1.f - fg), A.clip);
                 dg4[2] = clipf_(dct * ig * (1.f - gg * gg), A.clip);
@@ -602,15 +624,16 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             } else {
                 dh_pass = dh_t;
             }
-            da4 = dg4 * dh4;
+            da4 = dg4 * dh4e;
             dd_h = dg4 * a4; dd_x = dg4 * x4;
-            cs_h += dd_h; cs_x += dd_x; cs_g += dg4;
+            dd_b = A.lhuc ? f32x4{ds_pre, 0.f, 0.f, 0.f} : dg4;
+            cs_h += dd_h; cs_x += dd_x; cs_g += dd_b;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dal[(q * 4 + k) * 16 + bl] = da4[k];
                 dDl[0 * 256 + (q * 4 + k) * 16 + bl] = dd_h[k];
                 dDl[1 * 256 + (q * 4 + k) * 16 + bl] = dd_x[k];
-                dDl[2 * 256 + (q * 4 + k) * 16 + bl] = dg4[k];
+                dDl[2 * 256 + (q * 4 + k) * 16 + bl] = dd_b[k];
             }
             // all-gather payload: da of the own 16 columns in the operand order of the consumers'
             // 4x4x1 MFMAs (lane = ks*16 + b holds columns 4e+ks, e = 0..3): a 4x4 transpose through the
@@ -650,7 +673,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             float* dd_ = D.dD + row * 12 * N;
             *(f32x4*)(dd_ + col4) = dd_h;
             *(f32x4*)(dd_ + 4 * N + col4) = dd_x;
-            *(f32x4*)(dd_ + 8 * N + col4) = dg4;
+            *(f32x4*)(dd_ + 8 * N + col4) = dd_b;
         }
         if (!group_wait(gs)) break;
         STAMP(3);
@@ -836,6 +859,7 @@ struct asr_hyper_scan_desc {
     int T, B, N, H, ndir;
     float grad_clip;
     int clip_outcell;
+    int lhuc_reparam;            // 0: HyperLSTM / scaling; 1 relu, 2 exp, 3 identity, 4 2sigmoid: HyperLHUCLSTMLayer
     const float* mask; int mask_stride_b, mask_stride_t;
     HyperDir dir[2];
 };
@@ -877,6 +901,8 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     if (A.G * d->ndir > 256) return ASR_ERR_ARG;         // co-residency bound of the persistent grid
     A.T = d->T; A.B = d->B; A.ndir = d->ndir; A.clip = d->grad_clip;
     A.clip_out = d->clip_outcell ? d->grad_clip : 0.f;
+    if (d->lhuc_reparam < 0 || d->lhuc_reparam > 4) return ASR_ERR_ARG;
+    A.lhuc = d->lhuc_reparam;
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
     A.d[0] = d->dir[0]; A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
     const size_t per_wg = hyper_pack_floats_wg(A, backward);

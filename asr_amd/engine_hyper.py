@@ -41,14 +41,19 @@ def perm4(src, dst, rows, N, inverse=False):
 class HyperPair(object):
     kind = 'hyper'
     stateful = False
+    lhuc = 0                     # asr_hyper_scan_desc.lhuc_reparam
+    _mk = staticmethod(_mk_hyper)
 
     def __init__(self, net, idx, D, N, H, Z, clip, ndir):
         self.net = net; self.idx = idx
         self.D, self.N, self.H, self.Z = D, N, H, Z
         self.clip = float(clip); self.ndir = ndir
         self.out_dim = ndir * N
-        self.dirs = [_mk_hyper(net.store, 'L%d.%d.' % (idx, d), D, N, H, Z) for d in range(ndir)]
+        self.dirs = [self._mk(net.store, 'L%d.%d.' % (idx, d), D, N, H, Z) for d in range(ndir)]
         self.reverse = [False, True][:ndir]
+
+    def _xbias(self, dp):
+        return None
 
     def describe(self):
         out = {}
@@ -86,12 +91,12 @@ class HyperPair(object):
         Y = self._buf('Y', rows, self.out_dim)
         desc = _lib.HyperScanDesc()
         desc.T, desc.B, desc.N, desc.H, desc.ndir = T, B, N, H, self.ndir
-        desc.grad_clip = self.clip
+        desc.grad_clip = self.clip; desc.lhuc_reparam = self.lhuc
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
         self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[])
         for d, dp in enumerate(self.dirs):
             c = {}
-            c['xproj'] = ops.gemm(X, dp.p('Wx'), self._buf('xproj%d' % d, rows, 4 * N))
+            c['xproj'] = ops.gemm(X, dp.p('Wx'), self._buf('xproj%d' % d, rows, 4 * N), bias=self._xbias(dp))
             c['xhproj'] = ops.gemm(X, dp.p('Wxh')[N:], self._buf('xhproj%d' % d, rows, 4 * H), bias=dp.p('bh'))
             Mi = self._fold(dp, d)
             c['Mi'] = Mi
@@ -128,7 +133,7 @@ class HyperPair(object):
         rows = T * B
         desc = _lib.HyperScanDesc()
         desc.T, desc.B, desc.N, desc.H, desc.ndir = T, B, N, H, self.ndir
-        desc.grad_clip = self.clip
+        desc.grad_clip = self.clip; desc.lhuc_reparam = self.lhuc
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
         for d, dp in enumerate(self.dirs):
             c = ctx['d'][d]
@@ -179,6 +184,10 @@ class HyperPair(object):
             ops.gemm(X, dXh, gWxh[N:], ta=True)                               # dW_xhat (x rows)
             ops.colreduce(c['dbh'], dp.g('bh'), c['dbh'].shape[0], 4 * H)     # summed over time in the scan
             ops.gemm(Hh[sl_prev], dXh[sl_cur], dp.g('Whh'), ta=True)          # dW_hhat
+            self._fold_grads(dp, d, c, Hh, dD, rows)
+
+    def _fold_grads(self, dp, d, c, Hh, dD, rows):
+            N, H = self.N, self.H
             dMi = self._buf('dMi%d' % d, H + 1, 12 * N)
             ops.gemm(Hh, dD, dMi[:H], ta=True)
             ops.colreduce(c['dcv'], dMi[H], c['dcv'].shape[0], 12 * N)
@@ -193,3 +202,75 @@ class HyperPair(object):
                 ops.gemm(dMg[:H, 2, g, :], dp.p('Wzb')[g], dp.g('Wz_b')[g], tb=True)
                 ops.gemm(dp.p('Wz_b')[g], dMg[:H, 2, g, :], dp.g('Wzb')[g], ta=True)
             dp.g('b0').copy_(dMg[H, 2])
+
+
+# ------------------------------------------------------------------------------------------------
+REPARAM = {'relu': 1, 'exp': 2, 'identity': 3, '2sigmoid': 4}
+
+
+def _mk_hyperlhuc(store, prefix, D, N, H, Z):
+    dp = DirParams(store, prefix)
+    dp.add('Whh', (H, 4 * H)); dp.add('Wxh', (N + D, 4 * H)); dp.add('bh', (4 * H,))
+    dp.add('Wz', (H + 1, Z)); dp.add('Wzz', (Z, N))
+    dp.add('Wh', (N, 4 * N)); dp.add('Wx', (D, 4 * N)); dp.add('b', (4 * N,))
+    # reference add_param order: hyper_lhuc_layers.py:533-555, :521-525
+    for g, gn in enumerate(G4):
+        dp.map('W_hhat_' + gn, 'Whh', 'gatecols', g); dp.map('W_xhat_' + gn, 'Wxh', 'gatecols', g)
+        dp.map('bhat_' + gn, 'bh', 'gatevec', g)
+    dp.map('W_hhat_h', 'Wz', 'fn', lambda E: E[:-1]); dp.map('b_hhat_h', 'Wz', 'fn', lambda E: E[-1])
+    dp.map('W_hz', 'Wzz')
+    for g, gn in enumerate(G4):
+        dp.map('W_h_' + gn, 'Wh', 'gatecols', g); dp.map('W_x_' + gn, 'Wx', 'gatecols', g)
+        dp.map('b_' + gn, 'b', 'gatevec', g)
+    return dp
+
+
+class HyperLHUCPair(HyperPair):
+    """HyperLHUCLSTMLayer (libs/lasagne_libs/hyper_lhuc_layers.py:509-678) on the HyperLSTM scan kernel
+    in its lhuc mode: M (H+1, 12N) holds constants d_h = d_x = 1 (zero matrices, cvec rows = 1) and, in
+    gate column 0 of the bias tile, the folded LHUC map [W_hhat_h ; b_hhat_h] . W_hz (H+1, N)."""
+    kind = 'hyperlhuc'
+    _mk = staticmethod(_mk_hyperlhuc)
+
+    def __init__(self, net, idx, D, N, H, Z, clip, ndir, reparam='relu'):
+        HyperPair.__init__(self, net, idx, D, N, H, Z, clip, ndir)
+        self.reparam = reparam
+        self.lhuc = REPARAM[reparam]
+        self._tmpl = None
+
+    def describe(self):
+        out = HyperPair.describe(self)
+        for nm in ('fwd', 'bwd'):
+            if out[nm] is not None:
+                out[nm]['kind'] = 'hyperlhuc'
+                out[nm]['args']['reparam'] = self.reparam
+        return out
+
+    def _xbias(self, dp):
+        return dp.p('b')
+
+    def _fold(self, dp, d):
+        N, H = self.N, self.H
+        if self._tmpl is None:                   # constant part of M, gate-major: d_h = d_x = 1
+            import numpy as np
+            t = np.zeros((H + 1, 3, 4, N), np.float32)
+            t[H, 0] = 1.0; t[H, 1] = 1.0
+            self._tmpl = torch.from_numpy(t).to(self.net.device).view(H + 1, 12 * N)
+        Mg = self._buf('Mg%d' % d, H + 1, 12 * N)
+        Mg.copy_(self._tmpl)
+        ops.gemm(dp.p('Wz'), dp.p('Wzz'), Mg.view(H + 1, 3, 4, N)[:, 2, 0, :])
+        Mi = self._buf('Mi%d' % d, H + 1, 12 * N)
+        perm4(Mg, Mi, (H + 1) * 3, N)
+        return Mi
+
+    def _fold_grads(self, dp, d, c, Hh, dD, rows):
+        N, H = self.N, self.H
+        dMi = self._buf('dMi%d' % d, H + 1, 12 * N)
+        ops.gemm(Hh, dD, dMi[:H], ta=True)
+        ops.colreduce(c['dcv'], dMi[H], c['dcv'].shape[0], 12 * N)
+        dMg = self._buf('dMg%d' % d, H + 1, 12 * N)
+        perm4(dMi, dMg, (H + 1) * 3, N, inverse=True)
+        dMl = dMg.view(H + 1, 3, 4, N)[:, 2, 0, :]                      # d of the folded LHUC map
+        ops.gemm(dMl, dp.p('Wzz'), dp.g('Wz'), tb=True)
+        ops.gemm(dp.p('Wz'), dMl, dp.g('Wzz'), ta=True)
+        ops.colreduce(c['dXp'], dp.g('b'), rows, 4 * N)                 # d b_stacked (:645)

@@ -217,3 +217,17 @@ def scaling_hyper_params(D, H, N):
                 ('W_inner_hid_to_outer_hid_' + g, (H, N), ('const', 0.0)), ('b_inner_hid_to_outer_hid_' + g, (N,), ('const', 1.0)),
                 ('W_inner_hid_to_outer_bias_' + g, (H, N), 'orthogonal'), ('b_inner_hid_to_outer_bias_' + g, (N,), ('const', fb))]
     return out
+
+
+def hyperlhuc_params(D, N, H, Z, reparam='relu'):
+    """HyperLHUCLSTMLayer, libs/lasagne_libs/hyper_lhuc_layers.py:533-555 (init_weights, then
+    init_main_lstm_weights :521-525).  Gate.b defaults to Constant(0.) (lasagne Gate)."""
+    out = []
+    for g in GATES_LHUC:
+        out += [('W_hhat_' + g, (H, H), ('normal', 0.1)), ('W_xhat_' + g, (N + D, H), 'orthogonal'),
+                ('bhat_' + g, (H,), ('const', 0.0))]
+    out += [('W_hhat_h', (H, Z), ('const', 0.0)), ('b_hhat_h', (Z,), ('const', 1.0)),
+            ('W_hz', (Z, N), ('const', 1.0 / Z))]
+    for g in GATES_LHUC:
+        out += [('W_h_' + g, (N, N), ('normal', 0.1)), ('W_x_' + g, (D, N), 'orthogonal'), ('b_' + g, (N,), ('const', 0.0))]
+    return out

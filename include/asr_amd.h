@@ -188,7 +188,10 @@ typedef struct asr_hyper_scan_desc {
     int T, B, N, H, ndir;
     float grad_clip;
     int clip_outcell;         /* 1: also grad_clip the outcell of both cells (ScalingHyperLSTMLayer,
-                               * libs/lasagne_libs/hyper_layers.py:1023-1025,1083-1085) */
+                               * libs/lasagne_libs/hyper_layers.py:1016-1022,1083-1089) */
+    int lhuc_reparam;         /* 0, or HyperLHUCLSTMLayer (hyper_lhuc_layers.py:509-678): 1 relu, 2 exp, 3 identity,
+                               * 4 2sigmoid (:17-27).  M then carries d_h = d_x = 1 and the LHUC pre-scale in gate
+                               * column 0 of its bias tile; gates = h.W_h + xproj, h = o*tanh(c)*reparam(d) */
     const float* mask; int mask_stride_b, mask_stride_t;
     asr_hyper_dir dir[2];
 } asr_hyper_scan_desc;

@@ -295,6 +295,117 @@ def hyper_scan_bwd(dhid, x, fwd_cache, p, spec):
 
 
 # --------------------------------------------------------------------------------------------
+# HyperLHUCLSTMLayer scan (libs/lasagne_libs/hyper_lhuc_layers.py:509-678): the hyper cell of eq.10
+# (shared compute_eq10 :216-237), a PLAIN main LSTM (gates = h.W_h + x.W_x + b, one grad_clip on the
+# whole vector :593-597), and LHUC: hid = o*tanh(c) * reparam((hhat.W_hhat_h + b_hhat_h).W_hz), the
+# scaled hid being the recurrent state (:585-613).  reparam: relu | exp | identity | 2sigmoid (:17-27).
+# p keys: W_xhat (N+D,4H), bhat (4H), W_hhat (H,4H), W_hhat_h (H,Z), b_hhat_h (Z), W_hz (Z,N),
+#         W_h (N,4N), W_x (D,4N), b (4N)
+# --------------------------------------------------------------------------------------------
+def _reparam(kind, v):
+    if kind == 'relu':
+        return np.maximum(v, 0), (v > 0).astype(v.dtype)
+    if kind == 'exp':
+        e = np.exp(v); return e, e
+    if kind == 'identity':
+        return v, np.ones_like(v)
+    if kind == '2sigmoid':
+        sg = _sig(v); return 2 * sg, 2 * sg * (1 - sg)
+    raise KeyError(kind)
+
+
+def hyperlhuc_scan_fwd(x, mask, p, spec):
+    T, B, D = x.shape
+    N, H = spec['N'], spec['H']
+    dt = x.dtype
+    xproj = x @ p['W_x'] + p['b']                         # :645
+    hc = np.zeros((B, H), dt); hh = np.zeros((B, H), dt)
+    c = np.zeros((B, N), dt); h = np.zeros((B, N), dt)
+    order = range(T - 1, -1, -1) if spec.get('backwards') else range(T)
+    hid = np.zeros((T, B, N), dt)
+    cache = [None] * T
+    for t in order:
+        m = mask[t][:, None] != 0
+        hx = np.concatenate([h, x[t]], axis=1)
+        hg = hx @ p['W_xhat'] + p['bhat'] + hh @ p['W_hhat']
+        hi = _sig(hg[:, 0:H]); hf = _sig(hg[:, H:2 * H])
+        hgc = np.tanh(hg[:, 2 * H:3 * H]); ho = _sig(hg[:, 3 * H:4 * H])
+        hc_new = hf * hc + hi * hgc
+        thc = np.tanh(hc_new)
+        hh_new = ho * thc
+        z_h = hh_new @ p['W_hhat_h'] + p['b_hhat_h']      # :585
+        d_h = z_h @ p['W_hz']                             # :588
+        gates = h @ p['W_h'] + xproj[t]                   # :593
+        i = _sig(gates[:, 0:N]); f = _sig(gates[:, N:2 * N])
+        g = np.tanh(gates[:, 2 * N:3 * N]); o = _sig(gates[:, 3 * N:4 * N])
+        c_new = f * c + i * g                             # :606
+        tc = np.tanh(c_new)
+        r0 = o * tc                                       # :609
+        sc, dsc = _reparam(spec.get('reparam', 'relu'), d_h)
+        h_new = r0 * sc                                   # :612
+        cache[t] = (m, hc, hh, c, h, hx, hi, hf, hgc, ho, thc, hh_new, z_h, i, f, g, o, tc, r0, sc, dsc)
+        hc = np.where(m, hc_new, hc); hh = np.where(m, hh_new, hh)
+        c = np.where(m, c_new, c); h = np.where(m, h_new, h)
+        hid[t] = h
+    return hid, (cache, xproj)
+
+
+def hyperlhuc_scan_bwd(dhid, x, fwd_cache, p, spec):
+    cache, xproj = fwd_cache
+    T, B, D = x.shape
+    N, H = spec['N'], spec['H']
+    clipv = spec.get('grad_clip', 0)
+    dt = dhid.dtype
+    order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
+    g_ = {k: np.zeros_like(v) for k, v in p.items()}
+    dh = np.zeros((B, N), dt); dc = np.zeros((B, N), dt)
+    dhh = np.zeros((B, H), dt); dhc = np.zeros((B, H), dt)
+    dx = np.zeros((T, B, D), dt)
+    dxproj = np.zeros((T, B, 4 * N), dt)
+    for t in reversed(order):
+        (m, hc_prev, hh_prev, c_prev, h_prev, hx, hi, hf, hgc, ho, thc, hh_new, z_h, i, f, g, o, tc,
+         r0, sc, dsc) = cache[t]
+        dh_t = dhid[t] + dh
+        dh_new = np.where(m, dh_t, 0); dh_prev = np.where(m, 0, dh_t)
+        dc_new = np.where(m, dc, 0); dc_prev = np.where(m, 0, dc)
+        dhh_new = np.where(m, dhh, 0); dhh_prev = np.where(m, 0, dhh)
+        dhc_new = np.where(m, dhc, 0); dhc_prev = np.where(m, 0, dhc)
+        dr0 = dh_new * sc
+        dd_h = dh_new * r0 * dsc
+        do = dr0 * tc
+        dc_new = dc_new + dr0 * o * (1 - tc * tc)
+        dgates = np.concatenate([dc_new * g * i * (1 - i), dc_new * c_prev * f * (1 - f),
+                                 dc_new * i * (1 - g * g), do * o * (1 - o)], axis=1)
+        dgates = _clip(dgates, clipv)
+        dc_prev = dc_prev + dc_new * f
+        dxproj[t] = dgates
+        g_['W_h'] += h_prev.T @ dgates
+        dh_prev = dh_prev + dgates @ p['W_h'].T
+        g_['W_hz'] += z_h.T @ dd_h
+        dz_h = dd_h @ p['W_hz'].T
+        g_['W_hhat_h'] += hh_new.T @ dz_h; g_['b_hhat_h'] += dz_h.sum(0)
+        dhh_new = dhh_new + dz_h @ p['W_hhat_h'].T
+        dho = dhh_new * thc
+        dhc_new = dhc_new + dhh_new * ho * (1 - thc * thc)
+        dhg = np.concatenate([dhc_new * hgc * hi * (1 - hi), dhc_new * hc_prev * hf * (1 - hf),
+                              dhc_new * hi * (1 - hgc * hgc), dho * ho * (1 - ho)], axis=1)
+        dhg = _clip(dhg, clipv)
+        dhc_prev = dhc_prev + dhc_new * hf
+        g_['W_xhat'] += hx.T @ dhg
+        g_['bhat'] += dhg.sum(0)
+        g_['W_hhat'] += hh_prev.T @ dhg
+        dhx = dhg @ p['W_xhat'].T
+        dh_prev = dh_prev + dhx[:, :N]
+        dx[t] = dhx[:, N:]
+        dhh_prev = dhh_prev + dhg @ p['W_hhat'].T
+        dh, dc, dhh, dhc = dh_prev, dc_prev, dhh_prev, dhc_prev
+    g_['W_x'] += x.reshape(T * B, D).T @ dxproj.reshape(T * B, 4 * N)
+    g_['b'] += dxproj.sum((0, 1))
+    dx += dxproj @ p['W_x'].T
+    return dx, g_
+
+
+# --------------------------------------------------------------------------------------------
 # ScalingHyperLSTMLayer scan (libs/lasagne_libs/hyper_layers.py:850-1205) with use_peepholes=False and
 # use_layer_norm=False, the configuration models/gating_hyper_nets.py:27-38 defaults to: the cell-to
 # -gate vectors and the scale_outer_cell map are then non-trainable zeros (:585-588, :716-723) and
@@ -759,6 +870,37 @@ class HyperLSTMLayerO(OracleLayer):
         return _tm(dx)
 
 
+class HyperLHUCLSTMLayerO(OracleLayer):
+    """libs/lasagne_libs/hyper_lhuc_layers.py:509-678."""
+    def __init__(self, P, num_units, num_hyper_units, num_proj_units, grad_clipping=0, backwards=False,
+                 reparam='relu'):
+        self.P = P
+        self.spec = dict(N=num_units, H=num_hyper_units, Z=num_proj_units, grad_clip=grad_clipping,
+                         backwards=backwards, reparam=reparam)
+
+    def forward(self, x, mask, cond=None):
+        P = self.P; G4 = GATES_LHUC
+        self.p = dict(W_xhat=_stack(P, 'W_xhat_{}', G4), bhat=_stack(P, 'bhat_{}', G4, 0),
+                      W_hhat=_stack(P, 'W_hhat_{}', G4), W_hhat_h=P['W_hhat_h'], b_hhat_h=P['b_hhat_h'],
+                      W_hz=P['W_hz'], W_h=_stack(P, 'W_h_{}', G4), W_x=_stack(P, 'W_x_{}', G4),
+                      b=_stack(P, 'b_{}', G4, 0))
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        hid, self.cache = hyperlhuc_scan_fwd(self.x, m, self.p, self.spec)
+        return _tm(hid)
+
+    def backward(self, dy):
+        dx, g = hyperlhuc_scan_bwd(_tm(dy), self.x, self.cache, self.p, self.spec)
+        G = {}; G4 = GATES_LHUC
+        for nm in ('W_xhat', 'W_hhat', 'W_h', 'W_x'):
+            _unstack_into(G, nm + '_{}', G4, g[nm])
+        for nm in ('bhat', 'b'):
+            _unstack_into(G, nm + '_{}', G4, g[nm], axis=0)
+        for nm in ('W_hhat_h', 'b_hhat_h', 'W_hz'):
+            G[nm] = g[nm]
+        self.grads = G
+        return _tm(dx)
+
+
 class ScalingHyperLSTMLayerO(OracleLayer):
     """libs/lasagne_libs/hyper_layers.py:525-1205 (use_peepholes=False, use_layer_norm=False).  forward
     returns the OUTER hidden sequence (what models/gating_hyper_nets.py:66-98 feeds upward); the inner
@@ -896,7 +1038,8 @@ def gen_win(batch, win_size, right_context=0):
 # --------------------------------------------------------------------------------------------
 _KINDS = dict(lstm=LSTMLayerO, lhuc=LHUCLSTMLayerO, prj=ProjectLSTMLayerO,
               ln_prj=LayerNormProjectLSTMLayerO, icond_ln_prj=InputCondLayerNormProjectLSTMLayerO,
-              hyper=HyperLSTMLayerO, rec=RecLayerO, scaling=ScalingHyperLSTMLayerO)
+              hyper=HyperLSTMLayerO, rec=RecLayerO, scaling=ScalingHyperLSTMLayerO,
+              hyperlhuc=HyperLHUCLSTMLayerO)
 
 
 class OracleNetwork(object):

@@ -359,3 +359,42 @@ def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False):
     outs = _scan(step, [inner_input, outer_input, m], [z(H), z(H), z(N), z(N)], backwards)
     hid = outs[3].transpose(0, 1)
     return hid.flip(1) if backwards else hid
+
+
+def hyperlhuc_layer(P, x, mask, N, H, Z, clip=0, backwards=False, reparam='relu'):
+    """libs/lasagne_libs/hyper_lhuc_layers.py:580-678 (step, get_output_for), compute_eq10 :216-237,
+    reparam_* :17-27."""
+    W_h = _cat(P, 'W_h_{}', G_L); W_x = _cat(P, 'W_x_{}', G_L); b = _cat(P, 'b_{}', G_L, 0)
+    W_hhat = _cat(P, 'W_hhat_{}', G_L); W_xhat = _cat(P, 'W_xhat_{}', G_L); bhat = _cat(P, 'bhat_{}', G_L, 0)
+    rp = dict(relu=torch.relu, exp=torch.exp, identity=lambda v: v,
+              **{'2sigmoid': lambda v: 2 / (1 + torch.exp(-v))})[reparam]
+    orig = x.transpose(0, 1)
+    inp = orig @ W_x + b
+    m = mask.transpose(0, 1).unsqueeze(-1)
+    B = orig.shape[1]
+
+    def step(orig_input_n, input_n, mask_n, hc_prev, hh_prev, c_prev, h_prev):
+        hin = torch.cat([h_prev, orig_input_n], 1) @ W_xhat + bhat
+        hg = grad_clip(hin + hh_prev @ W_hhat, clip)
+        hig = torch.sigmoid(hg[:, 0:H]); hfg = torch.sigmoid(hg[:, H:2 * H])
+        hci = torch.tanh(hg[:, 2 * H:3 * H])
+        hc = hfg * hc_prev + hig * hci
+        hog = torch.sigmoid(hg[:, 3 * H:4 * H])
+        hh = hog * torch.tanh(hc)
+        z_h = hh @ P['W_hhat_h'] + P['b_hhat_h']
+        d_h = z_h @ P['W_hz']
+        gates = grad_clip(h_prev @ W_h + input_n, clip)
+        ig = torch.sigmoid(gates[:, 0:N]); fg = torch.sigmoid(gates[:, N:2 * N])
+        ci = torch.tanh(gates[:, 2 * N:3 * N])
+        cell = fg * c_prev + ig * ci
+        og = torch.sigmoid(gates[:, 3 * N:4 * N])
+        hid = og * torch.tanh(cell)
+        hid = hid * rp(d_h)
+        k = mask_n != 0
+        return [torch.where(k, hc, hc_prev), torch.where(k, hh, hh_prev),
+                torch.where(k, cell, c_prev), torch.where(k, hid, h_prev)]
+
+    z = lambda n: torch.zeros(B, n, dtype=x.dtype)
+    outs = _scan(step, [orig, inp, m], [z(H), z(H), z(N), z(N)], backwards)
+    hid_out = outs[3].transpose(0, 1)
+    return hid_out.flip(1) if backwards else hid_out

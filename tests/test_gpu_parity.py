@@ -259,6 +259,26 @@ def test_scaling_hyper_reference_widths():
     run_case(net, b, calibrate=True)
 
 
+@pytest.mark.parametrize('is_bidir,clip,reparam', [(True, 0.05, 'relu'), (False, 0.0, 'relu'), (True, 0.0, 'exp'),
+                                                    (True, 0.05, '2sigmoid'), (False, 0.0, 'identity')])
+def test_hyperlhuc_small(is_bidir, clip, reparam):
+    """HyperLHUCLSTMLayer (hyper_lhuc_layers.py:509-678) on the hyper scan's lhuc mode."""
+    from asr_amd.builders import build_deep_hyperlhuclstm
+    net = build_deep_hyperlhuclstm('hyperlhuc', None, None, 5, 2, 8, 4, 2, 6, clip, is_bidir, 0, reparam=reparam,
+                                   device=_dev(), seed=41)
+    perturb_params(net, 42, 0.15)
+    b = make_batch(np.random.default_rng(43), 3, 7, 5, 6)
+    run_case(net, b)
+
+
+def test_hyperlhuc_medium():
+    from asr_amd.builders import build_deep_hyperlhuclstm
+    net = build_deep_hyperlhuclstm('hyperlhuc', None, None, 11, 2, 64, 16, 8, 13, 1.0, True, 0, device=_dev(), seed=44)
+    perturb_params(net, 45, 0.03)
+    b = make_batch(np.random.default_rng(46), 18, 31, 11, 13)
+    run_case(net, b)
+
+
 def test_adam_step_matches_oracle():
     from asr_amd.builders import build_deep_lstm
     net = build_deep_lstm(None, None, 5, 1, 8, 0, 6, 0.0, False, False, 0, device=_dev(), seed=1)

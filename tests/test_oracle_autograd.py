@@ -118,6 +118,16 @@ def test_scaling_hyper_layer(backwards, clip):
     _check(lay, lambda Pt, x, m, c: R.scaling_hyper_layer(Pt, x, m, N, Hs, clip, backwards), P, b['x'], b['mask'])
 
 
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip,reparam', [(0, 'relu'), (0.3, 'relu'), (0.3, 'exp'), (0, '2sigmoid'), (0, 'identity')])
+def test_hyperlhuc_layer(backwards, clip, reparam):
+    rng = np.random.default_rng(23)
+    P = make_params(rng, specs.hyperlhuc_params(D, N, H, Z), perturb=0.3, scale=1.5)
+    b = make_batch(rng, B, T, D, C)
+    lay = O.HyperLHUCLSTMLayerO(P, N, H, Z, clip, backwards, reparam)
+    _check(lay, lambda Pt, x, m, c: R.hyperlhuc_layer(Pt, x, m, N, H, Z, clip, backwards, reparam), P, b['x'], b['mask'])
+
+
 def test_softmax_ce_and_adam():
     rng = np.random.default_rng(15)
     lg = rng.standard_normal((B, T, C)) * 3
