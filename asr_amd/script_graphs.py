@@ -21,7 +21,7 @@ def build_trainer(input_data, input_mask, target_data, target_mask, network_para
                   output_layer, cond_layer_list, feat_reg, weight_decay, updater, learning_rate,
                   max_grad_norm=0.0, load_updater_params=None):
     network = output_layer
-    if feat_reg and cond_layer_list:
+    if feat_reg:
         raise NotImplementedError('asr_amd: feat_reg != 0 (sample-feature variance term) is not implemented')
     if weight_decay and weight_decay > 0:
         raise NotImplementedError('asr_amd: weight_decay > 0 (L2 penalty) is not implemented')
@@ -44,7 +44,16 @@ def build_trainer(input_data, input_mask, target_data, target_mask, network_para
         out = torch.cat([ce, ok, gn, ym.sum().reshape(1)]).cpu().numpy()
         network.check_status()
         nfr = max(float(out[3]), 1.0)
-        return [np.float32(out[0] / nfr), np.float32(out[1] / nfr), np.float32(0.0), np.float32(out[2])]
+        # train_feat_loss (:120-127) is reported even at feat_reg = 0: -mean(var(sample_feat, axis=0))
+        # averaged over the conditioning layers; a host-side read-out of the pooled features
+        fl = 0.0
+        for cl in cond_layer_list or []:
+            f = cl.get_sample_feat()
+            f = f.detach().cpu().numpy() if hasattr(f, 'detach') else np.asarray(f)
+            fl += -float(np.mean(np.var(f.astype(np.float64), axis=0)))
+        if cond_layer_list:
+            fl /= len(cond_layer_list)
+        return [np.float32(out[0] / nfr), np.float32(out[1] / nfr), np.float32(fl), np.float32(out[2])]
 
     return training_fn, train_lr, updater_params
 
