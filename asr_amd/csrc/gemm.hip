@@ -67,6 +67,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         }
         return v;
     };
+    // interior tiles (whole tile in range, all loads aligned): straight-line 16-byte loads with no
+    // bounds logic at all.  Any branch behind a load makes hipcc wait for the load at the join, which
+    // would put the global latency of every K-tile in front of its MFMAs instead of behind them.
+    auto load_tiles_fast = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 256 + tid;
+            if (TA) ra[e] = *(const f32x4*)(A + (size_t)(k0 + idx / 32) * lda + m0 + (idx % 32) * 4);
+            else    ra[e] = *(const f32x4*)(A + (size_t)(m0 + idx / 4) * lda + k0 + (idx % 4) * 4);
+            if (TB) rb[e] = *(const f32x4*)(B + (size_t)(n0 + idx / 4) * ldb + k0 + (idx % 4) * 4);
+            else    rb[e] = *(const f32x4*)(B + (size_t)(k0 + idx / 32) * ldb + n0 + (idx % 32) * 4);
+        }
+    };
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -100,13 +113,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
     const int Ksave = K;
     K = kend;                                  // loads beyond kend read as zero
     const int nk = (kend - kbeg + BK - 1) / BK;
-    load_tiles(kbeg);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
-        const int lr = lane & 31, lk = lane >> 5;
+    const int lr = lane & 31, lk = lane >> 5;
+    auto mfma_tile = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 2) {
             float a0 = As[buf][ks + lk][wm * 64 + lr];
@@ -118,10 +126,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-            store_tiles(buf ^ 1);
-        }
+    };
+    // workgroup-uniform: the whole tile is in range and aligned; only a last partial K-tile is guarded
+    const int nk_full = (kend - kbeg) / BK;
+    const bool interior = vecA && vecB && (m0 + BM <= M) && (n0 + BN <= N) && nk_full > 0;
+    if (interior) {
+        load_tiles_fast(kbeg);
+        store_tiles(0);
         __syncthreads();
+        for (int kt = 0; kt + 1 < nk_full; ++kt) {
+            load_tiles_fast(kbeg + (kt + 1) * BK);          // in flight under this tile's 32 MFMAs
+            mfma_tile(kt & 1);
+            store_tiles((kt & 1) ^ 1);
+            __syncthreads();
+        }
+        if (nk > nk_full) {                                 // K tail: one guarded tile
+            load_tiles(kbeg + nk_full * BK);
+            mfma_tile((nk_full - 1) & 1);
+            store_tiles(nk_full & 1);
+            __syncthreads();
+            mfma_tile(nk_full & 1);
+        } else {
+            mfma_tile((nk_full - 1) & 1);
+        }
+    } else {
+        load_tiles(kbeg);
+        store_tiles(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+            mfma_tile(buf);
+            if (kt + 1 < nk) store_tiles(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     K = Ksave;
