@@ -115,16 +115,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int lr = lane & 31, lk = lane >> 5;
     auto mfma_tile = [&](int buf) {
+        // all LDS operands of the tile are requested up front (32 VGPRs): LDS returns in order, so the
+        // first MFMAs start after the first reads and the rest of the read latency hides under them
+        float a0[BK / 2], a1[BK / 2], b0[BK / 2], b1[BK / 2];
 #pragma unroll
-        for (int ks = 0; ks < BK; ks += 2) {
-            float a0 = As[buf][ks + lk][wm * 64 + lr];
-            float a1 = As[buf][ks + lk][wm * 64 + 32 + lr];
-            float b0 = Bs[buf][ks + lk][wn * 64 + lr];
-            float b1 = Bs[buf][ks + lk][wn * 64 + 32 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            a0[k2] = As[buf][2 * k2 + lk][wm * 64 + lr];
+            a1[k2] = As[buf][2 * k2 + lk][wm * 64 + 32 + lr];
+            b0[k2] = Bs[buf][2 * k2 + lk][wn * 64 + lr];
+            b1[k2] = Bs[buf][2 * k2 + lk][wn * 64 + 32 + lr];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k2], b0[k2], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k2], b1[k2], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k2], b0[k2], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k2], b1[k2], acc[1][1], 0, 0, 0);
         }
     };
     // workgroup-uniform: the whole tile is in range and aligned; only a last partial K-tile is guarded
@@ -135,8 +141,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         store_tiles(0);
         __syncthreads();
         for (int kt = 0; kt + 1 < nk_full; ++kt) {
-            load_tiles_fast(kbeg + (kt + 1) * BK);          // in flight under this tile's 32 MFMAs
-            mfma_tile(kt & 1);
+            load_tiles_fast(kbeg + (kt + 1) * BK);          // in flight under this tile's 32 MFMAs:
+            __builtin_amdgcn_sched_barrier(0);              // keep the scheduler from sinking the loads
+            mfma_tile(kt & 1);                              // to their first use behind the MFMAs
+            __builtin_amdgcn_sched_barrier(0);
             store_tiles((kt & 1) ^ 1);
             __syncthreads();
         }
