@@ -51,11 +51,21 @@ def build(cfg, device='cpu'):
             'IVectorLHUCLSTMLayer', None, None, D, 2, N, 0, C, 1, 5, 0, 0, 0, B, 0.05, False, False, I, True,
             device=device, seed=5)
         return net, 'ivec'
+    if cfg == 'a5b_scaling_hyper':                 # ScalingHyperLSTMLayer, inner width 6 (padded to 8 on the GPU)
+        return G.deep_scaling_hyper_model(None, None, D, C, [6, 4], [N, N], grad_clipping=0.05, device=device,
+                                          seed=6), None
+    if cfg == 'a5b_hyperlhuc':                     # HyperLHUCLSTMLayer, reparam relu
+        return builders.build_deep_hyperlhuclstm('hyperlhuc', None, None, D, 2, N, H, Z, C, 0.05, True, 0,
+                                                 device=device, seed=7), None
+    if cfg == 'a3_max_cond_ln':                    # MaxCondLayerNormProjectLSTMLayer + ProjectLSTMLayer
+        net, _ = G.deep_projection_max_cond_ln_model(None, None, D, C, 2, 1, F, N, grad_clipping=0.05, dropout=0.0,
+                                                     device=device, seed=8)
+        return net, None
     raise KeyError(cfg)
 
 
 CONFIGS = ['cfg1_lstm_bidir', 'cfg1_lstm_uni', 'cfg2_ln_lstmp', 'cfg3_hyperlstm', 'cfg4_ivec_ln_lstmp',
-           'cfg5_lhuc_tbptt']
+           'cfg5_lhuc_tbptt', 'a5b_scaling_hyper', 'a5b_hyperlhuc', 'a3_max_cond_ln']
 TBPTT = dict(cfg5_lhuc_tbptt=dict(win=3, right_context=0, T=8, lengths=[8, 1, 5]))
 
 
