@@ -749,6 +749,33 @@ class Network(object):
             self._ws[key] = ws
         return ws
 
+    def regularizable_ranges(self, is_reg):
+        """Flat-buffer ranges [lo, hi) of the engine tensors all of whose reference parameters are
+        regularizable (lasagne's `regularizable` tag, decided by `is_reg(ref_name)`).  An engine tensor
+        that mixes both kinds cannot be split into ranges and is refused."""
+        offs = {key: (off, off + (int(np.prod(shape)) + 3) // 4 * 4) for key, shape, off in self.store.entries}
+        out = []
+        for dp in self._all_dirparams():
+            flags = {}
+            for ref_name, name, kind, arg in dp.refmap:
+                flags.setdefault(name, set()).add(bool(is_reg(ref_name)))
+            for name, fl in flags.items():
+                if len(fl) > 1:
+                    raise NotImplementedError('asr_amd: engine tensor %s%s mixes regularizable and '
+                                              'non-regularizable reference parameters' % (dp.prefix, name))
+                if True in fl:
+                    out.append(offs[dp.keys[name]])
+        return out
+
+    def add_weight_decay(self, coef, is_reg):
+        """grad += 2*coef*param on the regularizable tensors: the gradient of lasagne's
+        apply_penalty(params, l2) * coef (scripts/dln/ted/exp_prj_lstm_dln.py:129-131).  Runs as the sgd
+        form of asr_opt_step with the roles swapped (g <- g - (-2 coef) p)."""
+        if not hasattr(self, '_wd_ranges'):
+            self._wd_ranges = self.regularizable_ranges(is_reg)
+        for lo, hi in self._wd_ranges:
+            ops.opt_step(0, self.store.g[lo:hi], self.store.p[lo:hi], None, None, -2.0 * float(coef), 0.0, 0.0, 0.0)
+
     def param_range(self, prefix):
         offs = [(off, off + (int(np.prod(shape)) + 3) // 4 * 4) for key, shape, off in self.store.entries
                 if key.startswith(prefix)]

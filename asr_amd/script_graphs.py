@@ -8,13 +8,31 @@ scripts/wsj/*.py): logits -> log-softmax CE, optional total_norm_constraint, `up
   eval_network(predict_fn, data_stream) -> (nll, fer)                                   (:186-215)
 
 Symbolic arguments are placeholders, as in asr_amd.comp_graph_utils.  Not on the HIP path yet and
-refused loudly: the sample-feature variance regulariser (`feat_reg != 0`, :120-127) and L2 weight decay
-(`weight_decay > 0`, :129-131)."""
+refused loudly: the sample-feature variance regulariser (`feat_reg != 0`, :120-127).  L2 weight decay
+(`weight_decay > 0`: `apply_penalty(network_reg_params, l2) * 10**(-weight_decay)`, :129-131) adds
+2*10**(-weight_decay)*W to the gradients of the regularizable parameters before the norm constraint."""
 import numpy as np
 import torch
 
 from .comp_graph_utils import _dev, _reducer
 from .updates import SharedScalar, total_norm_constraint
+
+
+_GATES = ('ingate', 'forgetgate', 'cell', 'outgate')
+
+
+def lasagne_regularizable(name):
+    """The `regularizable` tag of the parameters of libs/lasagne_libs/recurrent_layers.py and of
+    SequenceDenseLayer: add_param's default is True; False for the gate biases b_<gate> (:90,339,595),
+    b_cond_prj, b_beta, the LN betas W_beta_in / W_beta_hid / W_beta_cell (:624-659) and the cell beta the
+    v0_x cond classes register under the name "num_factors"; DenseLayer's b is False as well."""
+    if name in ('b', 'b_cond_prj', 'b_beta', 'num_factors'):
+        return False
+    if name.startswith('W_beta'):
+        return False
+    if name.startswith('b_') and name[2:] in _GATES:
+        return False
+    return True
 
 
 def build_trainer(input_data, input_mask, target_data, target_mask, network_params, network_reg_params,
@@ -23,8 +41,7 @@ def build_trainer(input_data, input_mask, target_data, target_mask, network_para
     network = output_layer
     if feat_reg:
         raise NotImplementedError('asr_amd: feat_reg != 0 (sample-feature variance term) is not implemented')
-    if weight_decay and weight_decay > 0:
-        raise NotImplementedError('asr_amd: weight_decay > 0 (L2 penalty) is not implemented')
+    wd_coef = 10.0 ** (-weight_decay) if (weight_decay and weight_decay > 0) else 0.0
     grads = None
     if max_grad_norm and max_grad_norm > 0.:
         grads, _ = total_norm_constraint(tensor_vars=None, max_norm=max_grad_norm, return_norm=True)
@@ -40,6 +57,8 @@ def build_trainer(input_data, input_mask, target_data, target_mask, network_para
                                  ym, cond=None, train=True)
         network.backward()
         red.finish()
+        if wd_coef:
+            network.add_weight_decay(wd_coef, lasagne_regularizable)
         gn = update.apply(network, want_sqrt=True)
         out = torch.cat([ce, ok, gn, ym.sum().reshape(1)]).cpu().numpy()
         network.check_status()

@@ -82,3 +82,26 @@ def test_script_trainer_momentum_clipped():
     ce, ces, opred, _ = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], None)
     assert abs(fl - ces / b['mask'].sum()) / (ces / b['mask'].sum()) < 2e-5
     assert ((pred.reshape(opred.shape) == opred) | (b['mask'] == 0)).all()
+
+
+def test_script_trainer_weight_decay():
+    """weight_decay (scripts/dln/ted/exp_prj_lstm_dln.py:129-131): one sgd step against the oracle with
+    2*10**(-wd)*W added to the gradients of the regularizable parameters."""
+    from asr_amd.gating_hyper_nets import deep_projection_ln_lstm_model
+    from asr_amd.script_graphs import build_trainer, lasagne_regularizable
+    from asr_amd.updates import sgd
+    net = deep_projection_ln_lstm_model(None, None, 5, 6, 2, 4, 8, grad_clipping=1.0, dropout=0.0, device='cuda:0', seed=33)
+    b = make_batch(np.random.default_rng(34), 3, 7, 5, 6)
+    params = net.get_all_params(trainable=True)
+    names = [n for n, _ in net.param_names_shapes()]
+    assert any(lasagne_regularizable(n) for n in names) and not all(lasagne_regularizable(n) for n in names)
+    fn, lr, upd = build_trainer(None, None, None, None, params, params, net, [], 0.0, 1, sgd, 0.1)
+    vals = [v.astype(np.float64) for v in net.get_all_param_values()]
+    onet = O.OracleNetwork(net.describe(), vals)
+    ce, ces, opred, og = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], None)
+    og = [g + (2 * 0.1 * v if lasagne_regularizable(n) else 0.0) for g, v, n in zip(og, vals, names)]
+    fl, acc, fr, gn = fn(b['x'], b['mask'], b['y'], b['mask'])
+    norm = np.sqrt(sum((g ** 2).sum() for g in og))
+    assert abs(gn - norm) / norm < 1e-4
+    for a, v, g in zip(net.get_all_param_values(), vals, og):
+        assert np.max(np.abs(a - (v - 0.1 * g))) < 2e-5 * max(1.0, np.max(np.abs(v)))

@@ -376,3 +376,26 @@ def test_transformers():
     assert list(TR.skip_frames_fixed([[np.arange(3)]], 1))[0][0][0].tolist() == [0, 1, 2]
     o = TR.unskip(np.arange(6, dtype=np.float32).reshape(1, 3, 2), 3, 7)
     assert o.shape == (1, 7, 2) and (o[0, 3] == o[0, 5]).all() and (o[0, 6] == [4, 5]).all()
+
+
+def test_regularizable_ranges_cover_the_rec_family():
+    """Every gating_hyper_nets builder maps lasagne's `regularizable` tag onto whole engine tensors."""
+    from asr_amd import gating_hyper_nets as G
+    from asr_amd.script_graphs import lasagne_regularizable
+    kw = dict(device='cpu', seed=1)
+    nets = [G.deep_projection_ln_lstm_model(None, None, 5, 6, 2, 4, 8, 1, 0.0, **kw),
+            G.deep_projection_lstm_model(None, None, 5, 6, 2, 4, 8, 1, 0.0, **kw),
+            G.deep_projection_ivector_ln_model(None, None, None, 5, 6, 2, 1, 3, 8, 1, 0.0, cond_dim=3, **kw)[0],
+            G.deep_projection_cond_ln_model(None, None, 5, 6, 2, 1, 3, 8, 1, 0.0, **kw)[0],
+            G.deep_projection_max_cond_ln_model(None, None, 5, 6, 2, 1, 3, 8, 1, 0.0, **kw)[0],
+            G.deep_lstm_model(None, None, 5, 6, 2, 8, 1, 0.0, **kw),
+            G.deep_ln_lstm_model(None, None, 5, 6, 2, 8, 1, 0.0, **kw),
+            G.deep_prj_lstm_dln_model_v2(None, None, 5, 6, 2, 1, 3, 8, 1, 0.0, **kw)[0]
+            if hasattr(G, 'deep_prj_lstm_dln_model_v2') else None]
+    for net in nets:
+        if net is None:
+            continue
+        rr = net.regularizable_ranges(lasagne_regularizable)
+        assert rr and all(lo % 4 == 0 and hi > lo for lo, hi in rr)
+        tot = sum(hi - lo for lo, hi in rr)
+        assert 0 < tot < net.store.size
