@@ -35,7 +35,7 @@ def scan_bytes_per_row_dir(backward):
     return 4 * words
 
 
-def cpu_baseline(net, sample_len=160):
+def cpu_baseline(net, sample_len=640):      # ~10 s of host work on the GPU box's 16 cores
     """Oracle (numpy fp32, host BLAS threads) fwd + BPTT + Adam on a bounded sample: the same batch
     truncated to `sample_len` frames per row."""
     from oracle import asr_oracle as O
