@@ -231,3 +231,24 @@ def hyperlhuc_params(D, N, H, Z, reparam='relu'):
     for g in GATES_LHUC:
         out += [('W_h_' + g, (N, N), ('normal', 0.1)), ('W_x_' + g, (D, N), 'orthogonal'), ('b_' + g, (N,), ('const', 0.0))]
     return out
+
+
+def prjhyper_params(D, F, N):
+    """ProjectionHyperLSTMLayer, libs/lasagne_libs/hyper_layers.py:55-208, trainable parameters in
+    add_param order.  The in-scale bias is registered under the NAME "b_outer_to_in_<gate>" (:135) but
+    bound to b_inner_to_in_<gate> (:160); the attribute name is used here.  Forget biases are 0 (the gate
+    helpers are called without bias_const, :81-99,164-194)."""
+    out = []
+    for g in GATES_REC:
+        out += [('W_in_to_inner_' + g, (D, N), 'orthogonal'), ('W_inner_to_inner_' + g, (F, N), 'orthogonal'),
+                ('W_outer_to_inner_' + g, (F, N), 'orthogonal'), ('b_inner_' + g, (N,), ('const', 0.0))]
+    out += [('W_inner_prj', (N, F), 'orthogonal'), ('W_inner_cell_ln', (N,), ('const', 1.0)),
+            ('b_inner_cell_ln', (N,), ('const', 0.0))]
+    for g in GATES_REC:
+        out += [('W_in_to_outer_' + g, (D, N), 'orthogonal'), ('W_outer_to_outer_' + g, (F, N), 'orthogonal'),
+                ('W_inner_to_in_' + g, (F, N), ('const', 0.0)), ('b_inner_to_in_' + g, (N,), ('const', 1.0)),
+                ('W_inner_to_outer_' + g, (F, N), ('const', 0.0)), ('b_inner_to_outer_' + g, (N,), ('const', 1.0)),
+                ('W_inner_to_bias_' + g, (F, N), 'orthogonal'), ('b_inner_to_bias_' + g, (N,), ('const', 0.0))]
+    out += [('W_outer_prj', (N, F), 'orthogonal'), ('W_outer_cell_ln', (N,), ('const', 1.0)),
+            ('b_outer_cell_ln', (N,), ('const', 0.0))]
+    return out

@@ -509,6 +509,115 @@ def scaling_scan_bwd(dhid_i, dhid_o, x, fwd_cache, p, spec):
 
 
 # --------------------------------------------------------------------------------------------
+# ProjectionHyperLSTMLayer scan (libs/lasagne_libs/hyper_layers.py:14-523, step :319-417): two N-unit
+# LSTMP cells with cell layer norm, both projected to F = num_factors.  The inner cell sees x_t, its own
+# projected hid and the outer projected hid (:329-331); three affine maps of the NEW inner hid scale the
+# outer cell's input term, recurrent term and bias (:367-377).  grad_clip on each gate pre-activation
+# and on each outcell (:338-350,358-361,384-396,404-407).  Output = [inner_hid | outer_hid] (:519).
+# p keys: Wi_x (D,4N), Wi_i (F,4N), Wi_o (F,4N), bi (4N), Wi_p (N,F), ai, bi_c (N,)  [inner cell LN]
+#         Wo_x (D,4N), Wo_o (F,4N), S (F,12N) = [to_in | to_outer | to_bias], s (12N), Wo_p (N,F), ao, bo_c
+# --------------------------------------------------------------------------------------------
+def prjhyper_scan_fwd(x, mask, p, spec):
+    T, B, D = x.shape
+    N, F = spec['N'], spec['F']
+    dt = x.dtype
+    inner_in = x @ p['Wi_x'] + p['bi']                    # :316
+    outer_in = x @ p['Wo_x']                              # :317
+    ic = np.zeros((B, N), dt); ih = np.zeros((B, F), dt)
+    oc = np.zeros((B, N), dt); oh = np.zeros((B, F), dt)
+    order = range(T - 1, -1, -1) if spec.get('backwards') else range(T)
+    hid_i = np.zeros((T, B, F), dt); hid_o = np.zeros((T, B, F), dt)
+    cache = [None] * T
+    for t in order:
+        m = mask[t][:, None] != 0
+        ig = inner_in[t] + ih @ p['Wi_i'] + oh @ p['Wi_o']                        # :329-331
+        ii = _sig(ig[:, 0:N]); if_ = _sig(ig[:, N:2 * N]); igc = np.tanh(ig[:, 2 * N:3 * N]); io = _sig(ig[:, 3 * N:4 * N])
+        ic_new = if_ * ic + ii * igc                                              # :355
+        iout, iln = ln_fwd(ic_new, p['ai'], p['bi_c'])                            # :357
+        itc = np.tanh(iout)
+        ir = io * itc                                                             # :363
+        ih_new = ir @ p['Wi_p']                                                   # :364
+        sc = ih_new @ p['S'] + p['s']                                             # :367
+        s_in, s_hid, s_b = sc[:, 0:4 * N], sc[:, 4 * N:8 * N], sc[:, 8 * N:12 * N]
+        a = oh @ p['Wo_o']
+        og = outer_in[t] * s_in + a * s_hid + s_b                                 # :375-377
+        oi = _sig(og[:, 0:N]); of = _sig(og[:, N:2 * N]); ogc = np.tanh(og[:, 2 * N:3 * N]); oo = _sig(og[:, 3 * N:4 * N])
+        oc_new = of * oc + oi * ogc                                               # :401
+        oout, oln = ln_fwd(oc_new, p['ao'], p['bo_c'])                            # :403
+        otc = np.tanh(oout)
+        orr = oo * otc                                                            # :409
+        oh_new = orr @ p['Wo_p']                                                  # :410
+        cache[t] = (m, ic, ih, oc, oh, ii, if_, igc, io, iln, itc, ir, ih_new, s_in, s_hid, a,
+                    oi, of, ogc, oo, oln, otc, orr)
+        ic = np.where(m, ic_new, ic); ih = np.where(m, ih_new, ih)                # :441-444
+        oc = np.where(m, oc_new, oc); oh = np.where(m, oh_new, oh)
+        hid_i[t] = ih; hid_o[t] = oh
+    return hid_i, hid_o, (cache, inner_in, outer_in)
+
+
+def prjhyper_scan_bwd(dhid_i, dhid_o, x, fwd_cache, p, spec):
+    cache, inner_in, outer_in = fwd_cache
+    T, B, D = x.shape
+    N, F = spec['N'], spec['F']
+    clipv = spec.get('grad_clip', 0)
+    dt = dhid_o.dtype
+    order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
+    g_ = {k: np.zeros_like(v) for k, v in p.items()}
+    doh = np.zeros((B, F), dt); doc = np.zeros((B, N), dt)
+    dih = np.zeros((B, F), dt); dic = np.zeros((B, N), dt)
+    d_ii = np.zeros((T, B, 4 * N), dt); d_oi = np.zeros((T, B, 4 * N), dt)
+    for t in reversed(order):
+        (m, ic_prev, ih_prev, oc_prev, oh_prev, ii, if_, igc, io, iln, itc, ir, ih_new, s_in, s_hid, a,
+         oi, of, ogc, oo, oln, otc, orr) = cache[t]
+        doh_t = dhid_o[t] + doh; dih_t = dhid_i[t] + dih
+        doh_new = np.where(m, doh_t, 0); doh_prev = np.where(m, 0, doh_t)
+        doc_new = np.where(m, doc, 0); doc_prev = np.where(m, 0, doc)
+        dih_new = np.where(m, dih_t, 0); dih_prev = np.where(m, 0, dih_t)
+        dic_new = np.where(m, dic, 0); dic_prev = np.where(m, 0, dic)
+        # outer cell
+        g_['Wo_p'] += orr.T @ doh_new
+        dorr = doh_new @ p['Wo_p'].T
+        doo = dorr * otc
+        dout = _clip(dorr * oo * (1 - otc * otc), clipv)
+        dcl, da_, db_ = ln_bwd(dout, p['ao'], oln)
+        g_['ao'] += da_.sum(0); g_['bo_c'] += db_.sum(0)
+        doc_new = doc_new + dcl
+        dog = np.concatenate([doc_new * ogc * oi * (1 - oi), doc_new * oc_prev * of * (1 - of),
+                              doc_new * oi * (1 - ogc * ogc), doo * oo * (1 - oo)], axis=1)
+        dog = _clip(dog, clipv)
+        doc_prev = doc_prev + doc_new * of
+        d_oi[t] = dog * s_in
+        dsc = np.concatenate([dog * outer_in[t], dog * a, dog], axis=1)
+        da = dog * s_hid
+        g_['Wo_o'] += oh_prev.T @ da
+        doh_prev = doh_prev + da @ p['Wo_o'].T
+        g_['S'] += ih_new.T @ dsc; g_['s'] += dsc.sum(0)
+        dih_new = dih_new + dsc @ p['S'].T
+        # inner cell
+        g_['Wi_p'] += ir.T @ dih_new
+        dir_ = dih_new @ p['Wi_p'].T
+        dio = dir_ * itc
+        diout = _clip(dir_ * io * (1 - itc * itc), clipv)
+        dcl, da_, db_ = ln_bwd(diout, p['ai'], iln)
+        g_['ai'] += da_.sum(0); g_['bi_c'] += db_.sum(0)
+        dic_new = dic_new + dcl
+        dig = np.concatenate([dic_new * igc * ii * (1 - ii), dic_new * ic_prev * if_ * (1 - if_),
+                              dic_new * ii * (1 - igc * igc), dio * io * (1 - io)], axis=1)
+        dig = _clip(dig, clipv)
+        dic_prev = dic_prev + dic_new * if_
+        d_ii[t] = dig
+        g_['Wi_i'] += ih_prev.T @ dig; g_['Wi_o'] += oh_prev.T @ dig
+        dih_prev = dih_prev + dig @ p['Wi_i'].T
+        doh_prev = doh_prev + dig @ p['Wi_o'].T
+        doh, doc, dih, dic = doh_prev, doc_prev, dih_prev, dic_prev
+    xf = x.reshape(T * B, D)
+    g_['Wi_x'] += xf.T @ d_ii.reshape(T * B, -1); g_['bi'] += d_ii.sum((0, 1))
+    g_['Wo_x'] += xf.T @ d_oi.reshape(T * B, -1)
+    dx = d_ii @ p['Wi_x'].T + d_oi @ p['Wo_x'].T
+    return dx, g_
+
+
+# --------------------------------------------------------------------------------------------
 # Layer wrappers.  Each takes x (B,T,D) batch-major like the reference layers, a parameter dict
 # keyed by the reference's add_param names, and returns (B,T,out) plus a cache for backward.
 # --------------------------------------------------------------------------------------------
@@ -897,6 +1006,47 @@ class HyperLHUCLSTMLayerO(OracleLayer):
             _unstack_into(G, nm + '_{}', G4, g[nm], axis=0)
         for nm in ('W_hhat_h', 'b_hhat_h', 'W_hz'):
             G[nm] = g[nm]
+        self.grads = G
+        return _tm(dx)
+
+
+class ProjectionHyperLSTMLayerO(OracleLayer):
+    """libs/lasagne_libs/hyper_layers.py:14-523.  forward returns [inner_hid | outer_hid] (:519); the
+    builder feeds the outer half upward (models/gating_hyper_nets.py:150-171).  Oracle only so far: the
+    HIP path for this class is not built yet."""
+    def __init__(self, P, num_factors, num_units, grad_clipping=0, backwards=False):
+        self.P = P
+        self.spec = dict(N=num_units, F=num_factors, grad_clip=grad_clipping, backwards=backwards)
+
+    def forward(self, x, mask, cond=None):
+        P = self.P; G = GATES_REC
+        S = np.concatenate([_stack(P, 'W_inner_to_in_{}', G), _stack(P, 'W_inner_to_outer_{}', G),
+                            _stack(P, 'W_inner_to_bias_{}', G)], axis=1)
+        sb = np.concatenate([_stack(P, 'b_inner_to_in_{}', G, 0), _stack(P, 'b_inner_to_outer_{}', G, 0),
+                             _stack(P, 'b_inner_to_bias_{}', G, 0)], axis=0)
+        self.p = dict(Wi_x=_stack(P, 'W_in_to_inner_{}', G), Wi_i=_stack(P, 'W_inner_to_inner_{}', G),
+                      Wi_o=_stack(P, 'W_outer_to_inner_{}', G), bi=_stack(P, 'b_inner_{}', G, 0),
+                      Wi_p=P['W_inner_prj'], ai=P['W_inner_cell_ln'], bi_c=P['b_inner_cell_ln'],
+                      Wo_x=_stack(P, 'W_in_to_outer_{}', G), Wo_o=_stack(P, 'W_outer_to_outer_{}', G),
+                      S=S, s=sb, Wo_p=P['W_outer_prj'], ao=P['W_outer_cell_ln'], bo_c=P['b_outer_cell_ln'])
+        self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
+        hi, ho, self.cache = prjhyper_scan_fwd(self.x, m, self.p, self.spec)
+        return np.concatenate([_tm(hi), _tm(ho)], axis=-1)
+
+    def backward(self, dy):
+        F = self.spec['F']; N = self.spec['N']
+        dyt = _tm(dy)
+        dx, g = prjhyper_scan_bwd(dyt[:, :, :F], dyt[:, :, F:], self.x, self.cache, self.p, self.spec)
+        G = {}; G4 = GATES_REC
+        for key, fmt in (('Wi_x', 'W_in_to_inner_{}'), ('Wi_i', 'W_inner_to_inner_{}'), ('Wi_o', 'W_outer_to_inner_{}'),
+                         ('Wo_x', 'W_in_to_outer_{}'), ('Wo_o', 'W_outer_to_outer_{}')):
+            _unstack_into(G, fmt, G4, g[key])
+        _unstack_into(G, 'b_inner_{}', G4, g['bi'], axis=0)
+        for k, nm in enumerate(('in', 'outer', 'bias')):
+            _unstack_into(G, 'W_inner_to_%s_{}' % nm, G4, g['S'][:, k * 4 * N:(k + 1) * 4 * N])
+            _unstack_into(G, 'b_inner_to_%s_{}' % nm, G4, g['s'][k * 4 * N:(k + 1) * 4 * N], axis=0)
+        G['W_inner_prj'] = g['Wi_p']; G['W_inner_cell_ln'] = g['ai']; G['b_inner_cell_ln'] = g['bi_c']
+        G['W_outer_prj'] = g['Wo_p']; G['W_outer_cell_ln'] = g['ao']; G['b_outer_cell_ln'] = g['bo_c']
         self.grads = G
         return _tm(dx)
 

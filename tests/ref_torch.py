@@ -398,3 +398,51 @@ def hyperlhuc_layer(P, x, mask, N, H, Z, clip=0, backwards=False, reparam='relu'
     outs = _scan(step, [orig, inp, m], [z(H), z(H), z(N), z(N)], backwards)
     hid_out = outs[3].transpose(0, 1)
     return hid_out.flip(1) if backwards else hid_out
+
+
+def prjhyper_layer(P, x, mask, N, F, clip=0, backwards=False):
+    """libs/lasagne_libs/hyper_layers.py:238-519 (get_output_for of ProjectionHyperLSTMLayer); ln :9-12."""
+    c = lambda fmt, dim=1: _cat(P, fmt, G_R, dim)
+    W_in_to_inner = c('W_in_to_inner_{}'); W_inner_to_inner = c('W_inner_to_inner_{}')
+    W_outer_to_inner = c('W_outer_to_inner_{}'); b_inner = c('b_inner_{}', 0)
+    W_in_to_outer = c('W_in_to_outer_{}'); W_outer_to_outer = c('W_outer_to_outer_{}')
+    W_inner_to_outer = torch.cat([c('W_inner_to_in_{}'), c('W_inner_to_outer_{}'), c('W_inner_to_bias_{}')], 1)
+    b_inner_to_outer = torch.cat([c('b_inner_to_in_{}', 0), c('b_inner_to_outer_{}', 0), c('b_inner_to_bias_{}', 0)], 0)
+    eps = float(torch.finfo(torch.float32).eps)
+
+    def ln(v, alpha, beta):
+        out = (v - v.mean(1, keepdim=True)) / torch.sqrt(v.var(1, unbiased=False, keepdim=True) + eps)
+        return alpha[None, :] * out + beta[None, :]
+
+    inp = x.transpose(0, 1)
+    m = mask.transpose(0, 1).unsqueeze(-1)
+    B = inp.shape[1]
+    inner_input = inp @ W_in_to_inner + b_inner
+    outer_input = inp @ W_in_to_outer
+    su = lambda v, n: v[:, n * N:(n + 1) * N]
+    sb = lambda v, n: v[:, 4 * n * N:4 * (n + 1) * N]
+
+    def step(inner_input_n, outer_input_n, mask_n, ic_prev, ih_prev, oc_prev, oh_prev):
+        ig = inner_input_n + ih_prev @ W_inner_to_inner + oh_prev @ W_outer_to_inner
+        i_in = torch.sigmoid(grad_clip(su(ig, 0), clip)); i_f = torch.sigmoid(grad_clip(su(ig, 1), clip))
+        i_c = grad_clip(su(ig, 2), clip); i_o = torch.sigmoid(grad_clip(su(ig, 3), clip))
+        inner_cell = i_f * ic_prev + i_in * torch.tanh(i_c)
+        inner_outcell = grad_clip(ln(inner_cell, P['W_inner_cell_ln'], P['b_inner_cell_ln']), clip)
+        inner_hid = (i_o * torch.tanh(inner_outcell)) @ P['W_inner_prj']
+        scale_outer = inner_hid @ W_inner_to_outer + b_inner_to_outer
+        og = outer_input_n * sb(scale_outer, 0) + (oh_prev @ W_outer_to_outer) * sb(scale_outer, 1) + sb(scale_outer, 2)
+        o_in = torch.sigmoid(grad_clip(su(og, 0), clip)); o_f = torch.sigmoid(grad_clip(su(og, 1), clip))
+        o_c = grad_clip(su(og, 2), clip); o_o = torch.sigmoid(grad_clip(su(og, 3), clip))
+        outer_cell = o_f * oc_prev + o_in * torch.tanh(o_c)
+        outer_outcell = grad_clip(ln(outer_cell, P['W_outer_cell_ln'], P['b_outer_cell_ln']), clip)
+        outer_hid = (o_o * torch.tanh(outer_outcell)) @ P['W_outer_prj']
+        k = mask_n != 0
+        return [torch.where(k, inner_cell, ic_prev), torch.where(k, inner_hid, ih_prev),
+                torch.where(k, outer_cell, oc_prev), torch.where(k, outer_hid, oh_prev)]
+
+    z = lambda n: torch.zeros(B, n, dtype=x.dtype)
+    outs = _scan(step, [inner_input, outer_input, m], [z(N), z(F), z(N), z(F)], backwards)
+    hi = outs[1].transpose(0, 1); ho = outs[3].transpose(0, 1)
+    if backwards:
+        hi = hi.flip(1); ho = ho.flip(1)
+    return torch.cat([hi, ho], -1)

@@ -128,6 +128,18 @@ def test_hyperlhuc_layer(backwards, clip, reparam):
     _check(lay, lambda Pt, x, m, c: R.hyperlhuc_layer(Pt, x, m, N, H, Z, clip, backwards, reparam), P, b['x'], b['mask'])
 
 
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip', [0, 0.3])
+def test_prjhyper_layer(backwards, clip):
+    """ProjectionHyperLSTMLayer (hyper_layers.py:14-523): oracle pinned ahead of its HIP path."""
+    rng = np.random.default_rng(29)
+    F_ = 3
+    P = make_params(rng, specs.prjhyper_params(D, F_, N), perturb=0.3, scale=1.5)
+    b = make_batch(rng, B, T, D, C)
+    lay = O.ProjectionHyperLSTMLayerO(P, F_, N, clip, backwards)
+    _check(lay, lambda Pt, x, m, c: R.prjhyper_layer(Pt, x, m, N, F_, clip, backwards), P, b['x'], b['mask'])
+
+
 def test_softmax_ce_and_adam():
     rng = np.random.default_rng(15)
     lg = rng.standard_normal((B, T, C)) * 3
