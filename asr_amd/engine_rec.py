@@ -282,6 +282,18 @@ class RecPair(object):
         ds = self._buf('ds%d' % d, B, F)
         for k, (nm, dv) in enumerate((('ai', dal_in), ('ah', dal_hid), ('bt', dbt))):
             ops.gemm(dv, dp.p('W' + nm), ds, tb=True, beta=0.0 if k == 0 else 1.0)
+        fr = getattr(self, 'feat_reg', 0.0)
+        if fr:
+            # + fr * d(-mean_j var_b s_bj)/ds = fr * (-2/(B F)) (I - 11^T/B) s: one more GEMM with the
+            # constant centring matrix (scripts/dln/ted/exp_prj_lstm_dln.py:120-131)
+            cm = self._centre.get(B) if hasattr(self, '_centre') else None
+            if cm is None:
+                import numpy as np
+                if not hasattr(self, '_centre'):
+                    self._centre = {}
+                cm = torch.from_numpy((np.eye(B) - 1.0 / B).astype(np.float32)).to(self.net.device)
+                self._centre[B] = cm
+            ops.gemm(cm, c['s'], ds, alpha=fr * (-2.0 / (B * F)), beta=1.0)
         sb, st, Tc, mode = c['pool']
         dpre = self._buf('dpre%d' % d, c['pre'].shape[0], F)
         ops.seq_pool_bwd(ds, c['s'], c['pre'], sb, st, self.ctx['mask'], B, Tc, F, mode, dpre)

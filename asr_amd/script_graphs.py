@@ -7,8 +7,9 @@ scripts/wsj/*.py): logits -> log-softmax CE, optional total_norm_constraint, `up
   build_predictor(...) -> predict_fn(x, mask, y, ymask) -> [frame_prd_idx, frame_loss]
   eval_network(predict_fn, data_stream) -> (nll, fer)                                   (:186-215)
 
-Symbolic arguments are placeholders, as in asr_amd.comp_graph_utils.  Not on the HIP path yet and
-refused loudly: the sample-feature variance regulariser (`feat_reg != 0`, :120-127).  L2 weight decay
+Symbolic arguments are placeholders, as in asr_amd.comp_graph_utils.  The sample-feature variance
+regulariser (`feat_reg`, :120-131) enters the backward pass of the conditioning layers as one more GEMM
+with the constant centring matrix.  L2 weight decay
 (`weight_decay > 0`: `apply_penalty(network_reg_params, l2) * 10**(-weight_decay)`, :129-131) adds
 2*10**(-weight_decay)*W to the gradients of the regularizable parameters before the norm constraint."""
 import numpy as np
@@ -39,8 +40,11 @@ def build_trainer(input_data, input_mask, target_data, target_mask, network_para
                   output_layer, cond_layer_list, feat_reg, weight_decay, updater, learning_rate,
                   max_grad_norm=0.0, load_updater_params=None):
     network = output_layer
-    if feat_reg:
-        raise NotImplementedError('asr_amd: feat_reg != 0 (sample-feature variance term) is not implemented')
+    if feat_reg and cond_layer_list:
+        for cl in cond_layer_list:             # train_feat_loss*feat_reg, averaged over the cond layers (:128)
+            if not hasattr(cl, 'pair') or not hasattr(cl.pair, '_cond_bwd'):
+                raise NotImplementedError('asr_amd: feat_reg needs the cond layers of asr_amd.engine_rec')
+            cl.pair.feat_reg = float(feat_reg) / len(cond_layer_list)
     wd_coef = 10.0 ** (-weight_decay) if (weight_decay and weight_decay > 0) else 0.0
     grads = None
     if max_grad_norm and max_grad_norm > 0.:

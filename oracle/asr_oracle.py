@@ -923,6 +923,9 @@ class RecLayerO(OracleLayer):
             else:
                 G['b_beta'] = dbeta.sum(0)
             ds = dal_in @ P['W_alpha_in'].T + dal_hid @ P['W_alpha_hid'].T + dbeta @ P['W_beta'].T
+            fr = getattr(self, 'feat_reg', 0.0)     # d/ds of fr * (-mean_j var_b s_bj): the scripts' train_feat_loss
+            if fr:                                  # (scripts/dln/ted/exp_prj_lstm_dln.py:120-131)
+                ds = ds + fr * (-2.0 / (sf.shape[0] * sf.shape[1])) * (sf - sf.mean(0, keepdims=True))
             if v['pool'] == 'mean_tanh':
                 da = (ds / self.msum)[:, None, :] * self.maskbt[:, :, None] * (1 - self.pre ** 2)
             else:      # T.max gradient goes to every position equal to the max, then relu'

@@ -105,3 +105,40 @@ def test_script_trainer_weight_decay():
     assert abs(gn - norm) / norm < 1e-4
     for a, v, g in zip(net.get_all_param_values(), vals, og):
         assert np.max(np.abs(a - (v - 0.1 * g))) < 2e-5 * max(1.0, np.max(np.abs(v)))
+
+
+def test_script_trainer_feat_reg():
+    """feat_reg (scripts/dln/ted/exp_prj_lstm_dln.py:120-131): train_feat_loss and its gradient through
+    the conditioning layers, one sgd step against the oracle."""
+    from asr_amd.gating_hyper_nets import deep_projection_cond_ln_model
+    from asr_amd.script_graphs import build_trainer
+    from asr_amd.updates import sgd
+    from test_gpu_parity import perturb_params
+    net, cond = deep_projection_cond_ln_model(None, None, 5, 6, 2, 2, 3, 8, grad_clipping=1.0, dropout=0.0,
+                                              device='cuda:0', seed=35)
+    perturb_params(net, 36, 0.15)
+    b = make_batch(np.random.default_rng(37), 4, 7, 5, 6)
+    params = net.get_all_params(trainable=True)
+    fr = 0.7
+    fn, lr, upd = build_trainer(None, None, None, None, params, params, net, cond, fr, 0, sgd, 0.1)
+    vals = [v.astype(np.float64) for v in net.get_all_param_values()]
+    onet = O.OracleNetwork(net.describe(), vals)
+    ncl = 0
+    for pair in onet.layers:
+        for lay in pair:
+            if lay is not None and getattr(lay, 'v', {}).get('cond'):
+                ncl += 1
+    assert ncl == len(cond) == 4
+    for pair in onet.layers:
+        for lay in pair:
+            if lay is not None and getattr(lay, 'v', {}).get('cond'):
+                lay.feat_reg = fr / ncl
+    ce, ces, opred, og = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], None)
+    ofl = np.mean([-np.mean(np.var(lay.get_sample_feat(), axis=0)) for pair in onet.layers for lay in pair
+                   if lay is not None and getattr(lay, 'v', {}).get('cond')])
+    fl, acc, tfl, gn = fn(b['x'], b['mask'], b['y'], b['mask'])
+    assert abs(tfl - ofl) < 2e-5 * max(1.0, abs(ofl))
+    norm = np.sqrt(sum((g ** 2).sum() for g in og))
+    assert abs(gn - norm) / norm < 1e-4
+    for a, v, g in zip(net.get_all_param_values(), vals, og):
+        assert np.max(np.abs(a - (v - 0.1 * g))) < 2e-5 * max(1.0, np.max(np.abs(v)))
