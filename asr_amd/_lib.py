@@ -35,6 +35,19 @@ class HyperDir(C.Structure):
                 ('dcv', fp), ('dbh', fp)]
 
 
+class PrjHyperDir(C.Structure):
+    _fields_ = [('reverse', i32)] + [(n, fp) for n in (
+        'inner_in', 'outer_in', 'Wio', 'Wi_p', 'S', 's', 'Wo_o', 'Wo_p', 'ai', 'bi_c', 'ao', 'bo_c', 'hid',
+        'gi', 'go', 'ci', 'co', 'ri', 'ro', 'xhi', 'xho', 'rsi', 'rso', 'sc', 'a',
+        'dhid', 'dii', 'doi', 'dsc', 'da', 'dh', 'douti', 'douto')]
+
+
+class PrjHyperDesc(C.Structure):
+    _fields_ = [('T', i32), ('B', i32), ('N', i32), ('F', i32), ('ndir', i32), ('b0', i32), ('Btot', i32),
+                ('grad_clip', f32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
+                ('dir', PrjHyperDir * 2)]
+
+
 class HyperScanDesc(C.Structure):
     _fields_ = [('T', i32), ('B', i32), ('N', i32), ('H', i32), ('ndir', i32), ('grad_clip', f32),
                 ('clip_outcell', i32), ('lhuc_reparam', i32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
@@ -61,6 +74,9 @@ _SIGS = {
     'asr_reduce_sum': (i32, [fp, sz, fp, i32, fp]),
     'asr_adam_step': (i32, [fp, fp, fp, fp, sz, f32, f32, f32, f32, fp, i32, fp, fp]),
     'asr_sqsum': (i32, [fp, sz, fp, i32, fp, fp]),
+    'asr_prjhyper_ws_bytes': (sz, [i32, i32, i32, i32]),
+    'asr_prjhyper_fwd': (i32, [C.POINTER(PrjHyperDesc), fp, sz, fp]),
+    'asr_prjhyper_bwd': (i32, [C.POINTER(PrjHyperDesc), fp, sz, fp]),
     'asr_opt_step': (i32, [i32, fp, fp, fp, fp, sz, f32, f32, f32, f32, fp, fp]),
     'asr_norm_clip_mult': (i32, [fp, f32, f32, fp, fp]),
     'asr_lstm_pack_floats': (sz, [i32, i32]),

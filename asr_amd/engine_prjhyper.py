@@ -1,0 +1,176 @@
+"""ProjectionHyperLSTMLayer pair (libs/lasagne_libs/hyper_layers.py:14-523) on the step-loop HIP path of
+asr_amd/csrc/step_prjhyper.hip.  Host side: the two all-timestep input projections (:316-317) before the
+loop, every parameter gradient and dX as large GEMMs over all T after it (deferred to the side stream
+where nothing below depends on them).  The layer's output fed upward is the OUTER hidden sequence of each
+direction (models/gating_hyper_nets.py:150-171); the inner one is kept for `get_inner_hid`.
+Gate vectors stay in the reference's gate-major layout here (no interleave)."""
+import ctypes as C
+import torch
+
+from . import _lib, ops, specs
+from ._lib import check
+from .engine import DirParams
+
+G4 = specs.GATES_REC
+
+
+def _mk_prj(store, prefix, D, N, F):
+    dp = DirParams(store, prefix)
+    dp.add('Wix', (D, 4 * N)); dp.add('Wio', (2 * F, 4 * N)); dp.add('bi', (4 * N,))
+    dp.add('Wip', (N, F)); dp.add('ai', (N,)); dp.add('bic', (N,))
+    dp.add('Wox', (D, 4 * N)); dp.add('Woo', (F, 4 * N)); dp.add('S', (F, 12 * N)); dp.add('s', (12 * N,))
+    dp.add('Wop', (N, F)); dp.add('ao', (N,)); dp.add('boc', (N,))
+    cb = lambda k: (lambda E: E[:, k * N:(k + 1) * N])            # column block k of a (., m*N) matrix
+    rcb = lambda r0, r1, k: (lambda E: E[r0:r1, k * N:(k + 1) * N])
+    vb = lambda k: (lambda E: E[k * N:(k + 1) * N])
+    # reference add_param order: hyper_layers.py:55-113 (inner), :118-208 (outer)
+    for g, gn in enumerate(G4):
+        dp.map('W_in_to_inner_' + gn, 'Wix', 'fn', cb(g))
+        dp.map('W_inner_to_inner_' + gn, 'Wio', 'fn', rcb(0, F, g))
+        dp.map('W_outer_to_inner_' + gn, 'Wio', 'fn', rcb(F, 2 * F, g))
+        dp.map('b_inner_' + gn, 'bi', 'fn', vb(g))
+    dp.map('W_inner_prj', 'Wip'); dp.map('W_inner_cell_ln', 'ai'); dp.map('b_inner_cell_ln', 'bic')
+    for g, gn in enumerate(G4):
+        dp.map('W_in_to_outer_' + gn, 'Wox', 'fn', cb(g))
+        dp.map('W_outer_to_outer_' + gn, 'Woo', 'fn', cb(g))
+        for k, nm in enumerate(('in', 'outer', 'bias')):
+            dp.map('W_inner_to_%s_%s' % (nm, gn), 'S', 'fn', cb(4 * k + g))
+            dp.map('b_inner_to_%s_%s' % (nm, gn), 's', 'fn', vb(4 * k + g))
+    dp.map('W_outer_prj', 'Wop'); dp.map('W_outer_cell_ln', 'ao'); dp.map('b_outer_cell_ln', 'boc')
+    return dp
+
+
+class PrjHyperPair(object):
+    kind = 'prjhyper'
+    stateful = False
+
+    def __init__(self, net, idx, D, N, F, clip, ndir):
+        if N % 4 or F % 4:
+            raise ValueError('asr_amd: ProjectionHyperLSTMLayer needs num_units and num_factors divisible by 4')
+        self.net = net; self.idx = idx
+        self.D, self.N, self.F = D, N, F
+        self.clip = float(clip); self.ndir = ndir
+        self.out_dim = ndir * F
+        self.dirs = [_mk_prj(net.store, 'L%d.%d.' % (idx, d), D, N, F) for d in range(ndir)]
+        self.reverse = [False, True][:ndir]
+
+    def describe(self):
+        out = {}
+        for d, nm in enumerate(('fwd', 'bwd')):
+            if d >= self.ndir:
+                out[nm] = None
+                continue
+            out[nm] = dict(kind='prjhyper',
+                           args=dict(num_factors=self.F, num_units=self.N, grad_clipping=self.clip,
+                                     backwards=self.reverse[d], only_outer=True),
+                           params=[r[0] for r in self.dirs[d].refmap])
+        return out
+
+    def _buf(self, name, rows, cols):
+        return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols)
+
+    def inner_hid(self, d):
+        return self.ctx['d'][d]['hid'][:, :self.F]
+
+    _SAVE = (('gi', 4), ('go', 4), ('ci', 1), ('co', 1), ('ri', 1), ('ro', 1), ('xhi', 1), ('xho', 1), ('sc', 12), ('a', 4))
+    _BWD = (('dii', 4), ('doi', 4), ('dsc', 12), ('da', 4), ('douti', 1), ('douto', 1))
+
+    def _desc(self, T, B, mask, backward):
+        N, F = self.N, self.F
+        desc = _lib.PrjHyperDesc()
+        desc.T, desc.N, desc.F, desc.ndir, desc.Btot = T, N, F, self.ndir, B
+        desc.grad_clip = self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        for d, dp in enumerate(self.dirs):
+            c = self.ctx['d'][d]
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            for f, key in (('Wio', 'Wio'), ('Wi_p', 'Wip'), ('S', 'S'), ('s', 's'), ('Wo_o', 'Woo'), ('Wo_p', 'Wop'),
+                           ('ai', 'ai'), ('bi_c', 'bic'), ('ao', 'ao'), ('bo_c', 'boc')):
+                setattr(Dd, f, dp.p(key).data_ptr())
+            for f in ('inner_in', 'outer_in', 'hid', 'rsi', 'rso') + tuple(n for n, _ in self._SAVE):
+                setattr(Dd, f, c[f].data_ptr())
+            if backward:
+                for f in ('dhid', 'dh') + tuple(n for n, _ in self._BWD):
+                    setattr(Dd, f, c[f].data_ptr())
+        return desc
+
+    def _run(self, desc, B, backward):
+        L = _lib.lib()
+        need = L.asr_prjhyper_ws_bytes(min(B, 16), self.N, self.F, self.ndir)
+        ws = self.net._workspace(('prjhyper', self.idx), need)
+        fn = L.asr_prjhyper_bwd if backward else L.asr_prjhyper_fwd
+        for b0 in range(0, B, 16):                      # batch rows are independent: chunks of <= 16 rows
+            desc.b0 = b0; desc.B = min(16, B - b0)
+            check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                  'asr_prjhyper_%s' % ('bwd' if backward else 'fwd'))
+
+    def forward(self, X, T, B, mask, cond, train):
+        N, F = self.N, self.F
+        rows = T * B
+        Y = self._buf('Y', rows, self.out_dim)
+        self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[])
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            c['inner_in'] = ops.gemm(X, dp.p('Wix'), self._buf('iin%d' % d, rows, 4 * N), bias=dp.p('bi'))
+            c['outer_in'] = ops.gemm(X, dp.p('Wox'), self._buf('oin%d' % d, rows, 4 * N))
+            c['hid'] = self._buf('hid%d' % d, rows, 2 * F)
+            c['rsi'] = self._buf('rsi%d' % d, rows, 1); c['rso'] = self._buf('rso%d' % d, rows, 1)
+            for nm, w in self._SAVE:
+                c[nm] = self._buf('%s%d' % (nm, d), rows, w * N)
+            ctx['d'].append(c)
+        self._run(self._desc(T, B, mask, False), B, False)
+        for d in range(self.ndir):                      # SliceLayer(num_factors:) + ConcatLayer
+            Y[:, d * F:(d + 1) * F].copy_(ctx['d'][d]['hid'][:, F:])
+        return Y
+
+    def backward(self, dY, need_dx=True):
+        net = self.net; ctx = self.ctx; N, F = self.N, self.F
+        X, T, B, mask = ctx['X'], ctx['T'], ctx['B'], ctx['mask']
+        rows = T * B
+        for d in range(self.ndir):
+            c = ctx['d'][d]
+            c['dhid'] = self._buf('dhid%d' % d, rows, 2 * F)
+            c['dhid'].zero_()
+            c['dhid'][:, F:].copy_(dY[:, d * F:(d + 1) * F])
+            c['dh'] = self._buf('dh%d' % d, rows, 2 * F)
+            for nm, w in self._BWD:
+                c[nm] = self._buf('%s%d' % (nm, d), rows, w * N)
+        self._run(self._desc(T, B, mask, True), B, True)
+        dX = self._buf('dX', rows, self.D) if need_dx else None
+        if need_dx:
+            for d, dp in enumerate(self.dirs):
+                c = ctx['d'][d]
+                ops.gemm(c['dii'], dp.p('Wix'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+                ops.gemm(c['doi'], dp.p('Wox'), dX, tb=True, beta=1.0)
+        with net.deferred():
+            self._param_grads(ctx, rows, T, B)
+        return dX
+
+    def _param_grads(self, ctx, rows, T, B):
+        N, F = self.N, self.F
+        X = ctx['X']
+        n1 = (T - 1) * B
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            hid, dh = c['hid'], c['dh']
+            if not self.reverse[d]:
+                sl_prev, sl_cur = slice(0, n1), slice(B, rows)
+            else:
+                sl_prev, sl_cur = slice(B, rows), slice(0, n1)
+            ops.gemm(X, c['dii'], dp.g('Wix'), ta=True)
+            ops.colreduce(c['dii'], dp.g('bi'), rows, 4 * N)
+            ops.gemm(X, c['doi'], dp.g('Wox'), ta=True)
+            if n1:
+                ops.gemm(hid[sl_prev], c['dii'][sl_cur], dp.g('Wio'), ta=True)
+                ops.gemm(hid[sl_prev][:, F:], c['da'][sl_cur], dp.g('Woo'), ta=True)
+            else:                                       # T == 1: no recurrent step ran
+                dp.g('Wio').zero_(); dp.g('Woo').zero_()
+            ops.gemm(c['ri'], dh[:, :F], dp.g('Wip'), ta=True)
+            ops.gemm(c['ro'], dh[:, F:], dp.g('Wop'), ta=True)
+            ops.gemm(hid[:, :F], c['dsc'], dp.g('S'), ta=True)
+            ops.colreduce(c['dsc'], dp.g('s'), rows, 12 * N)
+            ops.colreduce(c['douti'], dp.g('ai'), rows, N, y=c['xhi'])
+            ops.colreduce(c['douti'], dp.g('bic'), rows, N)
+            ops.colreduce(c['douto'], dp.g('ao'), rows, N, y=c['xho'])
+            ops.colreduce(c['douto'], dp.g('boc'), rows, N)

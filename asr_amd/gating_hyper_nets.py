@@ -293,3 +293,29 @@ class InnerHidHandle(object):
 
     def get_output(self):
         return self.pair.inner_hid(self.d)
+
+
+def deep_projection_hyper_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_factors, num_units,
+                                grad_clipping=1, device=None, seed=0):
+    """models/gating_hyper_nets.py:117-203 -> [output_layer, fwd_inner, bwd_inner]: the first layer is a
+    bidirectional ProjectionHyperLSTMLayer whose OUTER hidden sequences feed the stack, the remaining
+    layers are ProjectLSTMLayer(num_factors); logits output.  The inner entries have .get_output() ->
+    (T*B, num_factors) of the last forward."""
+    from .engine_prjhyper import PrjHyperPair
+    from .engine_rec import RecPair
+    net = Network(device or 'cuda:0')
+    D = num_inputs
+    inner = []
+    for l in range(num_layers):
+        if l == 0:
+            pair = PrjHyperPair(net, len(net.pairs), D, num_units, num_factors, grad_clipping or 0, 2)
+            net.add_pair(pair, [specs.prjhyper_params(D, num_factors, num_units)] * 2)
+            inner = [InnerHidHandle(pair, d) for d in range(2)]
+        else:
+            pair = RecPair(net, len(net.pairs), 'ProjectLSTMLayer', D, num_units, grad_clipping, 2,
+                           num_factors=num_factors)
+            net.add_pair(pair, [pair.spec_per_dir()] * 2)
+        D = pair.out_dim
+    net.set_output(D, num_outputs, 'logits')
+    net.finalize(seed)
+    return [net] + inner

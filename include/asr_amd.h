@@ -203,6 +203,47 @@ size_t asr_hyper_scan_ws_bytes(int T, int B, int N, int H, int ndir, int backwar
 int asr_hyper_scan_fwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 int asr_hyper_scan_bwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 
+/* ProjectionHyperLSTMLayer (libs/lasagne_libs/hyper_layers.py:14-523; step :319-417, step_masked
+ * :419-456): two N-unit cell-LN LSTMP cells coupled through three scale maps of the new inner hid.  First
+ * HIP path: the loop over T runs inside the library, one short chain of kernels per step (launch-bound).
+ * Gate vectors are gate-major [i|f|c|o] here.  One call handles batch rows [b0, b0+B), B <= 16. */
+typedef struct asr_prjhyper_dir {
+    int reverse;
+    const float* inner_in;    /* (T,Btot,4N) x.W_in_to_inner + b_inner (:316) */
+    const float* outer_in;    /* (T,Btot,4N) x.W_in_to_outer (:317) */
+    const float* Wio;         /* (2F,4N) [W_inner_to_inner ; W_outer_to_inner] */
+    const float* Wi_p;        /* (N,F) W_inner_prj */
+    const float* S;           /* (F,12N) [W_inner_to_in | W_inner_to_outer | W_inner_to_bias] */
+    const float* s;           /* (12N) */
+    const float* Wo_o;        /* (F,4N) W_outer_to_outer */
+    const float* Wo_p;        /* (N,F) W_outer_prj */
+    const float *ai, *bi_c, *ao, *bo_c;   /* cell layer norm alpha / beta (N) */
+    float* hid;               /* (T,Btot,2F) [inner_hid | outer_hid] (:519) */
+    float *gi, *go;           /* (T,Btot,4N) post-activation gates, saved for BPTT */
+    float *ci, *co;           /* (T,Btot,N) masked cell state */
+    float *ri, *ro;           /* (T,Btot,N) masked o*tanh(outcell) */
+    float *xhi, *xho;         /* (T,Btot,N) normalised cell */
+    float *rsi, *rso;         /* (T,Btot) rstd */
+    float* sc;                /* (T,Btot,12N) scale_outer */
+    float* a;                 /* (T,Btot,4N) outer_hid_prev . W_outer_to_outer */
+    const float* dhid;        /* backward: (T,Btot,2F) dLoss/d hid */
+    float *dii, *doi;         /* (T,Btot,4N) d inner gate pre-activations ; d outer_input */
+    float* dsc;               /* (T,Btot,12N) d scale_outer */
+    float* da;                /* (T,Btot,4N) */
+    float* dh;                /* (T,Btot,2F) total d hid_t */
+    float *douti, *douto;     /* (T,Btot,N) clipped d outcell */
+} asr_prjhyper_dir;
+typedef struct asr_prjhyper_desc {
+    int T, B, N, F, ndir;
+    int b0, Btot;
+    float grad_clip;
+    const float* mask; int mask_stride_b, mask_stride_t;
+    asr_prjhyper_dir dir[2];
+} asr_prjhyper_desc;
+size_t asr_prjhyper_ws_bytes(int B, int N, int F, int ndir);
+int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

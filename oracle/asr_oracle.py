@@ -1017,9 +1017,10 @@ class ProjectionHyperLSTMLayerO(OracleLayer):
     """libs/lasagne_libs/hyper_layers.py:14-523.  forward returns [inner_hid | outer_hid] (:519); the
     builder feeds the outer half upward (models/gating_hyper_nets.py:150-171).  Oracle only so far: the
     HIP path for this class is not built yet."""
-    def __init__(self, P, num_factors, num_units, grad_clipping=0, backwards=False):
+    def __init__(self, P, num_factors, num_units, grad_clipping=0, backwards=False, only_outer=False):
         self.P = P
         self.spec = dict(N=num_units, F=num_factors, grad_clip=grad_clipping, backwards=backwards)
+        self.only_outer = only_outer      # the builder's SliceLayer(indices=slice(num_factors, None)) (:150-152)
 
     def forward(self, x, mask, cond=None):
         P = self.P; G = GATES_REC
@@ -1034,11 +1035,14 @@ class ProjectionHyperLSTMLayerO(OracleLayer):
                       S=S, s=sb, Wo_p=P['W_outer_prj'], ao=P['W_outer_cell_ln'], bo_c=P['b_outer_cell_ln'])
         self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
         hi, ho, self.cache = prjhyper_scan_fwd(self.x, m, self.p, self.spec)
-        return np.concatenate([_tm(hi), _tm(ho)], axis=-1)
+        self.inner_hid = _tm(hi)
+        return _tm(ho) if self.only_outer else np.concatenate([_tm(hi), _tm(ho)], axis=-1)
 
     def backward(self, dy):
         F = self.spec['F']; N = self.spec['N']
         dyt = _tm(dy)
+        if self.only_outer:
+            dyt = np.concatenate([np.zeros_like(dyt), dyt], axis=-1)
         dx, g = prjhyper_scan_bwd(dyt[:, :, :F], dyt[:, :, F:], self.x, self.cache, self.p, self.spec)
         G = {}; G4 = GATES_REC
         for key, fmt in (('Wi_x', 'W_in_to_inner_{}'), ('Wi_i', 'W_inner_to_inner_{}'), ('Wi_o', 'W_outer_to_inner_{}'),
@@ -1192,7 +1196,7 @@ def gen_win(batch, win_size, right_context=0):
 _KINDS = dict(lstm=LSTMLayerO, lhuc=LHUCLSTMLayerO, prj=ProjectLSTMLayerO,
               ln_prj=LayerNormProjectLSTMLayerO, icond_ln_prj=InputCondLayerNormProjectLSTMLayerO,
               hyper=HyperLSTMLayerO, rec=RecLayerO, scaling=ScalingHyperLSTMLayerO,
-              hyperlhuc=HyperLHUCLSTMLayerO)
+              hyperlhuc=HyperLHUCLSTMLayerO, prjhyper=ProjectionHyperLSTMLayerO)
 
 
 class OracleNetwork(object):

@@ -279,6 +279,32 @@ def test_hyperlhuc_medium():
     run_case(net, b)
 
 
+@pytest.mark.parametrize('clip', [0.0, 0.05])
+def test_projection_hyper_small(clip):
+    """ProjectionHyperLSTMLayer (hyper_layers.py:14-523) on the step-loop HIP path + ProjectLSTMLayer on top."""
+    from asr_amd.gating_hyper_nets import deep_projection_hyper_model
+    out = deep_projection_hyper_model(None, None, 5, 6, 2, 4, 8, grad_clipping=clip, device=_dev(), seed=61)
+    net, inner = out[0], out[1:]
+    assert len(inner) == 2
+    perturb_params(net, 62, 0.15)
+    b = make_batch(np.random.default_rng(63), 3, 7, 5, 6)
+    run_case(net, b)
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    onet.posteriors(b['x'], b['mask'], None)
+    for d, h in enumerate(inner):
+        got = h.get_output().cpu().numpy().reshape(7, 3, -1).transpose(1, 0, 2)
+        assert relerr(got, onet.layers[0][d].inner_hid) < 2e-5
+
+
+def test_projection_hyper_medium():
+    """B = 18 (two batch chunks), N = 64, F = 32."""
+    from asr_amd.gating_hyper_nets import deep_projection_hyper_model
+    net = deep_projection_hyper_model(None, None, 11, 13, 2, 32, 64, grad_clipping=1.0, device=_dev(), seed=64)[0]
+    perturb_params(net, 65, 0.03)
+    b = make_batch(np.random.default_rng(66), 18, 21, 11, 13)
+    run_case(net, b, calibrate=True)
+
+
 def test_adam_step_matches_oracle():
     from asr_amd.builders import build_deep_lstm
     net = build_deep_lstm(None, None, 5, 1, 8, 0, 6, 0.0, False, False, 0, device=_dev(), seed=1)
