@@ -149,3 +149,13 @@ def test_cfg3_full_size_data_parallel_linearity():
     assert abs(ce_sum - ce_full) < 1e-5 * abs(ce_full)
     err = (acc - g_full).abs().max().item() / g_full.abs().max().item()
     assert err < 2e-5, err
+
+
+def test_projection_hyper_reference_width_vs_oracle():
+    """scripts/hypernets/exp_prj_hyper.py:30-34 defaults: 3 layers, 512 units, 256 factors, clip 1; B=16,
+    time axis truncated to 40 frames so the numpy oracle finishes in seconds."""
+    from asr_amd import gating_hyper_nets as G
+    net = G.deep_projection_hyper_model(None, None, 123, 3436, 3, 256, 512, grad_clipping=1.0, device=DEV, seed=31)[0]
+    perturb_params(net, 32, 0.01)
+    b = _batch(3, max_len=40)
+    run_case(net, b, calibrate=True)
