@@ -11,98 +11,175 @@
 // Layouts here are the reference's: gate vectors are gate-major [i | f | c | o] blocks of N, sequences
 // time-major (T,B,.).  The recurrent state that is carried is r = o*tanh(outcell) (N wide, masked like
 // the reference's hid): hid_t = r_t . W_prj is linear, so switching r is switching hid (:441-444).
-#include "common.h"
+#include "scan_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// C[Bm x Nc] = A[Bm x K] . W[K x Nc] (+ bias) (+ C if beta), Bm <= 16: one 16x16 MFMA tile per wave,
-// W streamed from L2, A re-read per k-step (a few KB, L1 resident).
-__global__ __launch_bounds__(256) void skinny_nn_kernel(const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ W, int ldw,
-                                                        const float* __restrict__ bias, float* __restrict__ Cm,
-                                                        int ldc, int Bm, int K, int Nc, int beta) {
+// Skinny products (<= 16 batch rows) of the step, both directions in one launch (blockIdx.z).  They are
+// L2-latency-bound, so the reduction axis is cut into 4 * nsplit slices: the 4 waves of a workgroup
+// reduce through LDS, the nsplit workgroups of an output block hand their partial blocks over in the
+// launch (cdna_hip_programming.md Guideline 16: 16-byte sc1 stores, vmcnt(0), one ticket atomic; the
+// last arriver sums the partials with sc1 loads IN SPLIT ORDER, so the result does not depend on
+// arrival order) -- no second launch, deterministic.
+#define SK_MAXP 2
+#define SK_TICKETS 4096
+#define SK_PART_FLOATS (512 * 1024)
+struct SkinnyProb { const float* A; const float* W; const float* bias; float* C; };
+struct SkinnyArgs {
+    SkinnyProb p[SK_MAXP];
+    int lda, ldw, ldc, Bm, K, Nc, beta, nsplit;     // K: reduction length, Nc: output columns
+    float* part; unsigned* tickets;
+};
+
+// true for the workgroup that must write the output block; acc then holds the full sum
+template <int NV>
+__device__ __forceinline__ bool skinny_combine(const SkinnyArgs& S, f32x4 (&acc)[NV], int blk, int nblk, int lane) {
+    if (S.nsplit == 1) return true;
+    const int split = blockIdx.y, prob = blockIdx.z;
+    const unsigned tile_bytes = 64u * NV * 16u;
+    const size_t slot = (size_t)(prob * nblk + blk) * S.nsplit;
+    __amdgpu_buffer_rsrc_t rs = make_rsrc_(S.part + slot * (64 * NV * 4), (unsigned)S.nsplit * tile_bytes);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) st_sc1_f4(rs, (unsigned)split * tile_bytes + (unsigned)(lane * NV + j) * 16u, acc[j]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned* tk = S.tickets + prob * nblk + blk;
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __shfl(old, 0);
+    if (old != (unsigned)S.nsplit - 1u) return false;
+    if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < S.nsplit; ++sp) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] += ld_sc1_f4(rs, (unsigned)sp * tile_bytes + (unsigned)(lane * NV + j) * 16u);
+    }
+    return true;
+}
+
+// C[Bm x Nc] = A[Bm x K] . W[K x Nc] (+ bias) (+ C if beta); Nc % 4 == 0, rows 16-byte aligned.
+// Workgroup = one 16 x 64 output block: lane (q, bl) owns rows 4q..4q+3 of columns n0+4bl..n0+4bl+3
+// (tile j of the four 16x16 MFMA tiles = columns n0+4bl+j: one 16-byte W load feeds four MFMAs).
+__global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
+    __shared__ f32x4 red[4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, bl = lane & 15;
-    const int n0 = (blockIdx.x * 4 + wave) * 16;
-    if (n0 >= Nc) return;
-    const int col = n0 + bl;
-    const bool cv = col < Nc, rv = bl < Bm;
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        float a[8], b[8];
+    const int blk = blockIdx.x;
+    const SkinnyProb& P = S.p[blockIdx.z];
+    const int col = blk * 64 + 4 * bl;
+    const bool cv = col < S.Nc, rv = bl < S.Bm;
+    const int ngrp = (S.K + 3) >> 2, nsl = 4 * S.nsplit;
+    const int per = (ngrp + nsl - 1) / nsl;
+    const int g0 = ((int)blockIdx.y * 4 + wave) * per;
+    const int g1 = min(g0 + per, ngrp);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {zero, zero, zero, zero};
+    const float* Ap = P.A + (size_t)bl * S.lda;
+    const float* Wp = P.W + col;
+    for (int g = g0; g < g1; g += 8) {
+        float a[8]; f32x4 w[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int k = k0 + 4 * s + q;
-            a[s] = (rv && k < K) ? A[(size_t)bl * lda + k] : 0.f;
-            b[s] = (cv && k < K) ? W[(size_t)k * ldw + col] : 0.f;
+            const int k = 4 * (g + s) + q;
+            const bool kv = (g + s) < g1 && k < S.K;
+            a[s] = (kv && rv) ? Ap[k] : 0.f;
+            w[s] = (kv && cv) ? *(const f32x4*)(Wp + (size_t)k * S.ldw) : zero;
         }
 #pragma unroll
-        for (int s = 0; s < 8; s += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[s][j], acc[j], 0, 0, 0);
         }
     }
-    const f32x4 acc = acc0 + acc1;                      // rows q*4..q*4+3 (batch), column bl
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
+    if (!skinny_combine<4>(S, acc, blk, gridDim.x, lane)) return;
     if (cv) {
-        const float bv = bias ? bias[col] : 0.f;
+        const f32x4 bv = P.bias ? *(const f32x4*)(P.bias + col) : zero;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = q * 4 + r;
-            if (row < Bm) {
-                float* p = Cm + (size_t)row * ldc + col;
-                *p = acc[r] + bv + (beta ? *p : 0.f);
+            if (row < S.Bm) {
+                f32x4* pc = (f32x4*)(P.C + (size_t)row * S.ldc + col);
+                f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                v += bv;
+                if (S.beta) v += *pc;
+                *pc = v;
             }
         }
     }
 }
 
-// C[Bm x Kc] = A[Bm x Nn] . W[Kc x Nn]^T (+ C if beta); Nn % 4 == 0, 16-byte aligned rows.
-__global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ W, int ldw,
-                                                        float* __restrict__ Cm, int ldc, int Bm, int Nn, int Kc,
-                                                        int beta) {
+// C[Bm x Nc] = A[Bm x K] . W[Nc x K]^T (+ C if beta); K % 4 == 0, rows 16-byte aligned.  Workgroup = one
+// 16-column output tile; the K axis goes in 64-column chunks (lane (q, bl): 64 contiguous bytes of row bl,
+// MFMA k index q <-> column 16q + 4e + i of the chunk).
+__global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
+    __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, bl = lane & 15;
-    const int k0 = (blockIdx.x * 4 + wave) * 16;
-    if (k0 >= Kc) return;
-    const int kout = k0 + bl;
-    const bool kv = kout < Kc, rv = bl < Bm;
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int g = 0; g < Nn; g += 16) {                  // MFMA k index q <-> columns g+4q .. g+4q+3
-        const int c = g + 4 * q;
-        f32x4 av = {0, 0, 0, 0}, wv = {0, 0, 0, 0};
-        if (c < Nn) {
-            if (rv) av = *(const f32x4*)(A + (size_t)bl * lda + c);
-            if (kv) wv = *(const f32x4*)(W + (size_t)kout * ldw + c);
+    const int blk = blockIdx.x;
+    const SkinnyProb& P = S.p[blockIdx.z];
+    const int kout = blk * 16 + bl;
+    const bool kv = kout < S.Nc, rv = bl < S.Bm;
+    const int nch = (S.K + 63) >> 6, nsl = 4 * S.nsplit;
+    const int per = (nch + nsl - 1) / nsl;
+    const int c0 = ((int)blockIdx.y * 4 + wave) * per;
+    const int c1 = min(c0 + per, nch);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = zero, acc1 = zero;
+    const float* Ap = P.A + (size_t)bl * S.lda + 16 * q;
+    const float* Wp = P.W + (size_t)kout * S.ldw + 16 * q;
+    for (int ch = c0; ch < c1; ch += 2) {
+        f32x4 av[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int off = (ch + u) * 64 + 4 * e;
+                const bool ok = (ch + u) < c1 && off + 16 * q < S.K;
+                av[u * 4 + e] = (ok && rv) ? *(const f32x4*)(Ap + off) : zero;
+                wv[u * 4 + e] = (ok && kv) ? *(const f32x4*)(Wp + off) : zero;
+            }
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wv[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wv[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wv[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wv[3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][0], wv[v][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][1], wv[v][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][2], wv[v][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][3], wv[v][3], acc1, 0, 0, 0);
+        }
     }
-    const f32x4 acc = acc0 + acc1;
+    red[wave][lane] = acc0 + acc1;
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 acc[1] = {red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]};
+    if (!skinny_combine<1>(S, acc, blk, gridDim.x, lane)) return;
     if (kv) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = q * 4 + r;
-            if (row < Bm) {
-                float* p = Cm + (size_t)row * ldc + kout;
-                *p = acc[r] + (beta ? *p : 0.f);
+            if (row < S.Bm) {
+                float* pc = P.C + (size_t)row * S.ldc + kout;
+                *pc = acc[0][r] + (S.beta ? *pc : 0.f);
             }
         }
     }
 }
 
-static int skinny_nn(const float* A, int lda, const float* W, int ldw, const float* bias, float* Cm, int ldc,
-                     int Bm, int K, int Nc, int beta, hipStream_t st) {
-    hipLaunchKernelGGL(skinny_nn_kernel, dim3((Nc + 63) / 64), dim3(256), 0, st, A, lda, W, ldw, bias, Cm, ldc, Bm, K,
-                       Nc, beta);
-    ASR_CHECK_LAUNCH();
-    return ASR_OK;
-}
-static int skinny_nt(const float* A, int lda, const float* W, int ldw, float* Cm, int ldc, int Bm, int Nn, int Kc,
-                     int beta, hipStream_t st) {
-    hipLaunchKernelGGL(skinny_nt_kernel, dim3((Kc + 63) / 64), dim3(256), 0, st, A, lda, W, ldw, Cm, ldc, Bm, Nn, Kc,
-                       beta);
+// np problems of one shape (the directions) in one launch
+static int skinny(bool nt, SkinnyArgs& S, int np, hipStream_t st) {
+    const int nblk = nt ? (S.Nc + 15) / 16 : (S.Nc + 63) / 64;
+    const int maxsplit = nt ? S.K / 256 : S.K / 64;
+    int ns = 512 / (np * nblk);
+    if (ns > maxsplit) ns = maxsplit;
+    if (ns < 1 || np * nblk > SK_TICKETS) ns = 1;
+    while (ns > 1 && (size_t)np * nblk * ns * (nt ? 256 : 1024) > SK_PART_FLOATS) --ns;
+    S.nsplit = ns;
+    if (nt) hipLaunchKernelGGL(skinny_nt_kernel, dim3(nblk, ns, np), dim3(256), 0, st, S);
+    else hipLaunchKernelGGL(skinny_nn_kernel, dim3(nblk, ns, np), dim3(256), 0, st, S);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
@@ -313,18 +390,29 @@ struct asr_prjhyper_desc {      // mirrored in include/asr_amd.h
 };
 
 extern "C" size_t asr_prjhyper_ws_bytes(int B, int N, int F, int ndir) {
-    return ((size_t)ndir * B * (4 * N + 4 * N + 2 * F) + (size_t)B * 2 * F) * sizeof(float) + 256;
+    return ((size_t)ndir * B * (4 * N + 4 * N + 2 * F) + (size_t)B * 2 * F + SK_PART_FLOATS) * sizeof(float) +
+           SK_TICKETS * sizeof(unsigned) + 256;
 }
 
 static int prj_check(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes) {
     if (!d || !ws || d->T < 0 || d->B <= 0 || d->B > 16 || d->N <= 0 || d->F <= 0 || (d->N & 3) || (d->F & 3) ||
-        d->N > 256 * PRJ_MAXU || d->ndir < 1 || d->ndir > 2 || !d->mask || d->b0 < 0 || d->b0 + d->B > d->Btot)
+        d->N > 256 * PRJ_MAXU || d->ndir < 1 || d->ndir > 2 || !d->mask || d->b0 < 0 || d->b0 + d->B > d->Btot ||
+        ((uintptr_t)ws & 15))
         return ASR_ERR_ARG;
     if (ws_bytes < asr_prjhyper_ws_bytes(d->B, d->N, d->F, d->ndir)) return ASR_ERR_WS;
     return ASR_OK;
 }
 
-static void prj_args(const asr_prjhyper_desc* d, void* ws, PrjArgs& A, float** zeros) {
+struct PrjHost {
+    PrjArgs A;
+    float* zeros;               // (B,2F) zeros: hid before the first step
+    float* part; unsigned* tickets;
+    int nd;
+    hipStream_t st;
+};
+
+static int prj_args(const asr_prjhyper_desc* d, void* ws, hipStream_t st, PrjHost& H) {
+    PrjArgs& A = H.A;
     A.T = d->T; A.B = d->B; A.N = d->N; A.F = d->F; A.ndir = d->ndir; A.clip = d->grad_clip;
     A.b0 = d->b0; A.Btot = d->Btot;
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
@@ -334,10 +422,38 @@ static void prj_args(const asr_prjhyper_desc* d, void* ws, PrjArgs& A, float** z
     A.tg = p; p += 4 * bn;
     A.g_c[0] = p; p += bn; A.g_c[1] = p; p += bn; A.g_r[0] = p; p += bn; A.g_r[1] = p; p += bn;
     A.g_h = p; p += (size_t)d->ndir * d->B * 2 * d->F;
-    *zeros = p;                                        // (B,2F) zeros: hid before the first step
+    H.zeros = p; p += (size_t)d->B * 2 * d->F;
+    H.part = p; p += SK_PART_FLOATS;
+    H.tickets = (unsigned*)p;
+    H.nd = d->ndir; H.st = st;
+    // the tickets start at zero (every launch leaves them at zero again)
+    if (hipMemsetAsync(H.tickets, 0, SK_TICKETS * sizeof(unsigned), st) != hipSuccess) return ASR_ERR_LAUNCH;
+    return ASR_OK;
 }
 
-// Batches of more than 16 rows are run by the caller in chunks of <= 16 rows (pointers advanced).
+// one skinny product per direction, one launch: pointers by direction
+static int prj_mm(PrjHost& H, bool nt, const float* const A[2], int lda, const float* const W[2], int ldw,
+                  const float* const bias[2], float* const Cm[2], int ldc, int K, int Nc, int beta) {
+    SkinnyArgs S;
+    for (int k = 0; k < SK_MAXP; ++k) {
+        const int kk = k < H.nd ? k : 0;
+        S.p[k].A = A[kk]; S.p[k].W = W[kk]; S.p[k].bias = bias ? bias[kk] : nullptr; S.p[k].C = Cm[kk];
+    }
+    S.lda = lda; S.ldw = ldw; S.ldc = ldc; S.Bm = H.A.B; S.K = K; S.Nc = Nc; S.beta = beta; S.nsplit = 1;
+    S.part = H.part; S.tickets = H.tickets;
+    return skinny(nt, S, H.nd, H.st);
+}
+
+static void prj_times(const asr_prjhyper_desc* d, PrjArgs& A, int step) {
+    const int T = d->T;
+    for (int k = 0; k < d->ndir; ++k) {
+        A.t[k] = A.d[k].reverse ? T - 1 - step : step;
+        A.tp[k] = step == 0 ? -1 : (A.d[k].reverse ? A.t[k] + 1 : A.t[k] - 1);
+    }
+    if (d->ndir == 1) { A.t[1] = A.t[0]; A.tp[1] = A.tp[0]; }
+}
+
+// Batches of more than 16 rows are run by the caller in chunks of <= 16 rows (b0 advanced).
 extern "C" int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
     int rc = prj_check(d, ws, ws_bytes);
     if (rc) return rc;
@@ -349,43 +465,38 @@ extern "C" int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
             return ASR_ERR_ARG;
     }
     if (d->T == 0) return ASR_OK;
-    PrjArgs A; float* zeros;
-    prj_args(d, ws, A, &zeros);
+    PrjHost H;
+    if ((rc = prj_args(d, ws, st, H))) return rc;
+    PrjArgs& A = H.A;
     const int T = d->T, B = d->B, N = d->N, F = d->F;
-    if (hipMemsetAsync(zeros, 0, (size_t)B * 2 * F * sizeof(float), st) != hipSuccess) return ASR_ERR_LAUNCH;
+    if (hipMemsetAsync(H.zeros, 0, (size_t)B * 2 * F * sizeof(float), st) != hipSuccess) return ASR_ERR_LAUNCH;
     for (int step = 0; step < T; ++step) {
-        for (int k = 0; k < d->ndir; ++k) {
-            A.t[k] = A.d[k].reverse ? T - 1 - step : step;
-            A.tp[k] = step == 0 ? -1 : (A.d[k].reverse ? A.t[k] + 1 : A.t[k] - 1);
+        prj_times(d, A, step);
+        const float *hprev[2], *ohprev[2], *ri[2], *ro[2], *hrow_c[2];
+        const float *Wio[2], *Wip[2], *Sm[2], *sb[2], *Woo[2], *Wop[2];
+        float *tg[2], *hrow[2], *ohrow[2], *sc[2], *a[2];
+        for (int k = 0; k < 2; ++k) {
+            const int kk = k < d->ndir ? k : 0;
+            const PrjDir& D = A.d[kk];
+            const size_t row0 = (size_t)A.t[kk] * d->Btot + d->b0;
+            hprev[k] = A.tp[kk] < 0 ? H.zeros : D.hid + ((size_t)A.tp[kk] * d->Btot + d->b0) * 2 * F;
+            ohprev[k] = hprev[k] + F;
+            hrow[k] = D.hid + row0 * 2 * F; hrow_c[k] = hrow[k]; ohrow[k] = hrow[k] + F;
+            ri[k] = D.ri + row0 * N; ro[k] = D.ro + row0 * N;
+            sc[k] = D.sc + row0 * 12 * N; a[k] = D.a + row0 * 4 * N;
+            tg[k] = A.tg + (size_t)kk * B * 4 * N;
+            Wio[k] = D.Wio; Wip[k] = D.Wi_p; Sm[k] = D.S; sb[k] = D.s; Woo[k] = D.Wo_o; Wop[k] = D.Wo_p;
         }
-        if (d->ndir == 1) { A.t[1] = A.t[0]; A.tp[1] = A.tp[0]; }
-        for (int k = 0; k < d->ndir; ++k) {              // recurrent part of the inner gates
-            const PrjDir& D = A.d[k];
-            const float* hprev = A.tp[k] < 0 ? zeros : D.hid + ((size_t)A.tp[k] * d->Btot + d->b0) * 2 * F;
-            if ((rc = skinny_nn(hprev, 2 * F, D.Wio, 4 * N, nullptr, A.tg + (size_t)k * B * 4 * N, 4 * N, B, 2 * F, 4 * N,
-                                0, st))) return rc;
-        }
+        // recurrent part of the inner gates                                                      :329-331
+        if ((rc = prj_mm(H, false, hprev, 2 * F, Wio, 4 * N, nullptr, tg, 4 * N, 2 * F, 4 * N, 0))) return rc;
         hipLaunchKernelGGL(prj_cell_fwd_kernel<0>, dim3(B, d->ndir), dim3(256), 0, st, A);
         ASR_CHECK_LAUNCH();
-        for (int k = 0; k < d->ndir; ++k) {
-            const PrjDir& D = A.d[k];
-            float* hrow = D.hid + ((size_t)A.t[k] * d->Btot + d->b0) * 2 * F;
-            const float* hprev = A.tp[k] < 0 ? zeros : D.hid + ((size_t)A.tp[k] * d->Btot + d->b0) * 2 * F;
-            const size_t row0 = (size_t)A.t[k] * d->Btot + d->b0;
-            if ((rc = skinny_nn(D.ri + row0 * N, N, D.Wi_p, F, nullptr, hrow, 2 * F, B, N, F, 0, st))) return rc;   // :364
-            if ((rc = skinny_nn(hrow, 2 * F, D.S, 12 * N, D.s, D.sc + row0 * 12 * N, 12 * N, B, F, 12 * N, 0, st)))  // :367
-                return rc;
-            if ((rc = skinny_nn(hprev + F, 2 * F, D.Wo_o, 4 * N, nullptr, D.a + row0 * 4 * N, 4 * N, B, F, 4 * N, 0, st)))
-                return rc;
-        }
+        if ((rc = prj_mm(H, false, ri, N, Wip, F, nullptr, hrow, 2 * F, N, F, 0))) return rc;            // :364
+        if ((rc = prj_mm(H, false, hrow_c, 2 * F, Sm, 12 * N, sb, sc, 12 * N, F, 12 * N, 0))) return rc;  // :367-370
+        if ((rc = prj_mm(H, false, ohprev, 2 * F, Woo, 4 * N, nullptr, a, 4 * N, F, 4 * N, 0))) return rc;  // :376
         hipLaunchKernelGGL(prj_cell_fwd_kernel<1>, dim3(B, d->ndir), dim3(256), 0, st, A);
         ASR_CHECK_LAUNCH();
-        for (int k = 0; k < d->ndir; ++k) {
-            const PrjDir& D = A.d[k];
-            const size_t row0 = (size_t)A.t[k] * d->Btot + d->b0;
-            if ((rc = skinny_nn(D.ro + row0 * N, N, D.Wo_p, F, nullptr, D.hid + row0 * 2 * F + F, 2 * F, B, N, F, 0, st)))  // :410
-                return rc;
-        }
+        if ((rc = prj_mm(H, false, ro, N, Wop, F, nullptr, ohrow, 2 * F, N, F, 0))) return rc;           // :410
     }
     return ASR_OK;
 }
@@ -401,45 +512,43 @@ extern "C" int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
             return ASR_ERR_ARG;
     }
     if (d->T == 0) return ASR_OK;
-    PrjArgs A; float* zeros;
-    prj_args(d, ws, A, &zeros);
+    PrjHost H;
+    if ((rc = prj_args(d, ws, st, H))) return rc;
+    PrjArgs& A = H.A;
     const int T = d->T, B = d->B, N = d->N, F = d->F;
     // carried gradients start at zero (tg is not used backward)
     if (hipMemsetAsync(A.g_c[0], 0, ((size_t)4 * d->ndir * B * N + (size_t)d->ndir * B * 2 * F) * sizeof(float), st) !=
         hipSuccess)
         return ASR_ERR_LAUNCH;
     for (int step = T - 1; step >= 0; --step) {
-        for (int k = 0; k < d->ndir; ++k) {
-            A.t[k] = A.d[k].reverse ? T - 1 - step : step;
-            A.tp[k] = step == 0 ? -1 : (A.d[k].reverse ? A.t[k] + 1 : A.t[k] - 1);
+        prj_times(d, A, step);
+        const float *dh_i[2], *dh_o[2], *dsc[2], *dii[2], *da[2];
+        const float *Wio[2], *Wip[2], *Sm[2], *Woo[2], *Wop[2];
+        float *dh_iw[2], *gr0[2], *gr1[2], *gh[2], *gh_o[2];
+        for (int k = 0; k < 2; ++k) {
+            const int kk = k < d->ndir ? k : 0;
+            const PrjDir& D = A.d[kk];
+            const size_t row0 = (size_t)A.t[kk] * d->Btot + d->b0;
+            dh_iw[k] = D.dh + row0 * 2 * F; dh_i[k] = dh_iw[k]; dh_o[k] = dh_iw[k] + F;
+            dsc[k] = D.dsc + row0 * 12 * N; dii[k] = D.dii + row0 * 4 * N; da[k] = D.da + row0 * 4 * N;
+            gr0[k] = A.g_r[0] + (size_t)kk * B * N; gr1[k] = A.g_r[1] + (size_t)kk * B * N;
+            gh[k] = A.g_h + (size_t)kk * B * 2 * F; gh_o[k] = gh[k] + F;
+            Wio[k] = D.Wio; Wip[k] = D.Wi_p; Sm[k] = D.S; Woo[k] = D.Wo_o; Wop[k] = D.Wo_p;
         }
-        if (d->ndir == 1) { A.t[1] = A.t[0]; A.tp[1] = A.tp[0]; }
         hipLaunchKernelGGL(prj_dh_kernel, dim3(4, d->ndir), dim3(256), 0, st, A);
         ASR_CHECK_LAUNCH();
-        for (int k = 0; k < d->ndir; ++k) {              // d r_out (total) += d outer_hid . W_outer_prj^T
-            const PrjDir& D = A.d[k];
-            const float* dh = D.dh + ((size_t)A.t[k] * d->Btot + d->b0) * 2 * F;
-            if ((rc = skinny_nt(dh + F, 2 * F, D.Wo_p, F, A.g_r[1] + (size_t)k * B * N, N, B, F, N, 1, st))) return rc;
-        }
+        // d r_out (total) += d outer_hid . W_outer_prj^T
+        if ((rc = prj_mm(H, true, dh_o, 2 * F, Wop, F, nullptr, gr1, N, F, N, 1))) return rc;
         hipLaunchKernelGGL(prj_cell_bwd_kernel<1>, dim3(B, d->ndir), dim3(256), 0, st, A);
         ASR_CHECK_LAUNCH();
-        for (int k = 0; k < d->ndir; ++k) {
-            const PrjDir& D = A.d[k];
-            float* dh = D.dh + ((size_t)A.t[k] * d->Btot + d->b0) * 2 * F;
-            const size_t row0 = (size_t)A.t[k] * d->Btot + d->b0;
-            // d inner_hid_t += d scale_outer . S^T ; d r_in (total) += d inner_hid . W_inner_prj^T
-            if ((rc = skinny_nt(D.dsc + row0 * 12 * N, 12 * N, D.S, 12 * N, dh, 2 * F, B, 12 * N, F, 1, st))) return rc;
-            if ((rc = skinny_nt(dh, 2 * F, D.Wi_p, F, A.g_r[0] + (size_t)k * B * N, N, B, F, N, 1, st))) return rc;
-        }
+        // d inner_hid_t += d scale_outer . S^T ; d r_in (total) += d inner_hid . W_inner_prj^T
+        if ((rc = prj_mm(H, true, dsc, 12 * N, Sm, 12 * N, nullptr, dh_iw, 2 * F, 12 * N, F, 1))) return rc;
+        if ((rc = prj_mm(H, true, dh_i, 2 * F, Wip, F, nullptr, gr0, N, F, N, 1))) return rc;
         hipLaunchKernelGGL(prj_cell_bwd_kernel<0>, dim3(B, d->ndir), dim3(256), 0, st, A);
         ASR_CHECK_LAUNCH();
-        for (int k = 0; k < d->ndir; ++k) {              // d hid_{t-1} = d inner gates . Wio^T ; oh half += da . Wo_o^T
-            const PrjDir& D = A.d[k];
-            const size_t row0 = (size_t)A.t[k] * d->Btot + d->b0;
-            float* gh = A.g_h + (size_t)k * B * 2 * F;
-            if ((rc = skinny_nt(D.dii + row0 * 4 * N, 4 * N, D.Wio, 4 * N, gh, 2 * F, B, 4 * N, 2 * F, 0, st))) return rc;
-            if ((rc = skinny_nt(D.da + row0 * 4 * N, 4 * N, D.Wo_o, 4 * N, gh + F, 2 * F, B, 4 * N, F, 1, st))) return rc;
-        }
+        // d hid_{t-1} = d inner gates . Wio^T ; its outer half += da . Wo_o^T
+        if ((rc = prj_mm(H, true, dii, 4 * N, Wio, 4 * N, nullptr, gh, 2 * F, 4 * N, 2 * F, 0))) return rc;
+        if ((rc = prj_mm(H, true, da, 4 * N, Woo, 4 * N, nullptr, gh_o, 2 * F, 4 * N, F, 1))) return rc;
     }
     return ASR_OK;
 }

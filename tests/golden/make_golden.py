@@ -61,11 +61,14 @@ def build(cfg, device='cpu'):
         net, _ = G.deep_projection_max_cond_ln_model(None, None, D, C, 2, 1, F, N, grad_clipping=0.05, dropout=0.0,
                                                      device=device, seed=8)
         return net, None
+    if cfg == 'a5b_projection_hyper':              # ProjectionHyperLSTMLayer (4 factors) + ProjectLSTMLayer
+        return G.deep_projection_hyper_model(None, None, D, C, 2, 4, N, grad_clipping=0.05, device=device,
+                                             seed=9)[0], None
     raise KeyError(cfg)
 
 
 CONFIGS = ['cfg1_lstm_bidir', 'cfg1_lstm_uni', 'cfg2_ln_lstmp', 'cfg3_hyperlstm', 'cfg4_ivec_ln_lstmp',
-           'cfg5_lhuc_tbptt', 'a5b_scaling_hyper', 'a5b_hyperlhuc', 'a3_max_cond_ln']
+           'cfg5_lhuc_tbptt', 'a5b_scaling_hyper', 'a5b_hyperlhuc', 'a3_max_cond_ln', 'a5b_projection_hyper']
 TBPTT = dict(cfg5_lhuc_tbptt=dict(win=3, right_context=0, T=8, lengths=[8, 1, 5]))
 
 
@@ -127,7 +130,7 @@ def generate(cfg):
 
 
 def main():
-    for cfg in CONFIGS:
+    for cfg in (sys.argv[1:] or CONFIGS):          # optional: names of the configs to (re)generate
         out = generate(cfg)
         path = os.path.join(HERE, cfg + '.npz')
         np.savez_compressed(path, **out)
