@@ -1,6 +1,7 @@
 """Condenses the rocprofv3 output of tools/profile_bench.sh into the small files kept under profiles/:
   <tag>_bench_kernel_stats.csv   the --stats kernel table as rocprofv3 wrote it
   <tag>_bench_pmc_hbm.csv        per kernel: launches, FETCH_SIZE and WRITE_SIZE (KB, average per launch)
+  <tag>_bench_pmc_mfma.csv       per kernel: derived MfmaUtil (%) and the raw MFMA counters, average per launch
   <tag>_pmc_hyper_scan_bwd.json  the dominant kernel's two figures, read by bench.py for roofline.traffic
 usage: python tools/summarize_prof.py <prof_dir> <tag> <out_dir>"""
 import csv, glob, json, os, shutil, sys
@@ -35,6 +36,23 @@ def main():
         for k in names:
             fh.write('"%s",%d,%.1f,%.1f\n' % (k, max(fe.get(k, (0, 0))[0], wr.get(k, (0, 0))[0]),
                                               fe.get(k, (0, 0))[1], wr.get(k, (0, 0))[1]))
+    mu = pmc(os.path.join(prof, 'pmc_mfmautil'), 'MfmaUtil')
+    raw = {c: pmc(os.path.join(prof, 'pmc_mfmaraw'), c) for c in
+           ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F32', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE')}
+    if mu or any(raw.values()):
+        ks = sorted(set(mu) | set(raw['SQ_VALU_MFMA_BUSY_CYCLES']))
+        with open(os.path.join(out, tag + '_bench_pmc_mfma.csv'), 'w') as fh:
+            # time-weighted utilisation = sum(MFMA busy) / (sum(GRBM_GUI_ACTIVE) / 8 XCDs * 1024 SIMDs): rocprofv3's
+            # MfmaUtil expression (reduce(GUI_ACTIVE,max) * SIMD_NUM) applied to the launch totals, so that the
+            # many tiny launches do not weigh as much as the big ones
+            fh.write('kernel,launches,MfmaUtil_pct_avg_per_launch,MfmaUtil_pct_time_weighted,' +
+                     ','.join(c + '_avg_per_launch' for c in raw) + '\n')
+            for k in ks:
+                gui = raw['GRBM_GUI_ACTIVE'].get(k, (0, 0))[1]
+                busy = raw['SQ_VALU_MFMA_BUSY_CYCLES'].get(k, (0, 0))[1]
+                fh.write('"%s",%d,%.2f,%.2f,%s\n' % (k, mu.get(k, (0, 0))[0] or raw['GRBM_GUI_ACTIVE'].get(k, (0, 0))[0],
+                                                mu.get(k, (0, 0))[1], 100.0 * busy / (gui / 8.0 * 1024.0) if gui else 0.0,
+                                                ','.join('%.0f' % raw[c].get(k, (0, 0))[1] for c in raw)))
     for kname in ('hyper_scan_bwd_kernel', 'hyper_scan_fwd_kernel'):
         if kname in fe and kname in wr:
             json.dump({'kernel': kname,
