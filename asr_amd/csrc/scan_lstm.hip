@@ -47,6 +47,7 @@ struct LstmScanArgs {
     int T, B, N, UT, G, KS, KSP, KT;
     int ndir, nchunk, chunk0;
     int ln_kind;             // 0 none, 1 static alpha[,beta], 2 per-sample alpha
+    unsigned long long* dbg; // STAMP_BYTES at the workspace tail (diagnostic builds)
     int per_gate;            // LN statistics per gate (gate_ln / sample_gate_ln) instead of per row
     int cell_ln;
     float clip;
@@ -107,43 +108,85 @@ extern "C" int asr_lstm_pack_w(const float* W, int N, int mode, float* out, hipS
 // ------------------------------------------------------------------------------------------------
 // Combine per-tile (mean, M2) statistics (equal counts cnt per tile) into the row mean / rstd over
 // all KS tiles.  Called by a whole epilogue wave; lane (q,bl) returns the stats of batch row bl.
-__device__ __forceinline__ void combine_stats(const float* st, int KS, int lane, float cnt,
-                                              float& mean, float& rstd, int tstride = 32) {
-    const int q = lane >> 4, bl = lane & 15;
-    float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
-    for (int s0 = q; s0 < KS; s0 += 32) {
-        float mj[8], M2j[8];
+// The per-tile pairs are read with sc1 BUFFER loads, all issued before the first use and with no branch
+// around any of them (tiles beyond KS fall outside the descriptor's range and read as 0): the conditional
+// 8-byte atomic loads this replaces were waited for one by one, ~20k cycles per call at KS = 128.
+// ALL FOUR WAVES of the workgroup take part (call it outside any `wave < UT` branch): wave w, lane (q, bl)
+// sums tiles 16 i + 4 w + q of batch row bl, the four partial sums meet in LDS (`scr`, 256 floats, free at
+// the call sites; the caller's next barrier precedes its next write).
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+template <int COMBINE_CHUNK, typename F>
+__device__ __forceinline__ void for_tile_pairs(const float* st, int KS, int tstride, int first, int stride, int bl,
+                                               F&& f) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc_(st, (unsigned)(((KS - 1) * tstride + 32) * 4));
+    const unsigned voff = (unsigned)((first * tstride + bl * 2) * 4);
+    for (int s0 = 0; s0 < KS; s0 += stride * COMBINE_CHUNK) {
+        u32x2_ v[COMBINE_CHUNK];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            mj[i] = 0.f; M2j[i] = 0.f;
-            if (s0 + 4 * i < KS) ld_sc1_f2(st + (size_t)(s0 + 4 * i) * tstride + bl * 2, mj[i], M2j[i]);
-        }
+        for (int i = 0; i < COMBINE_CHUNK; ++i)
+            v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)((s0 + stride * i) * tstride * 4), 16);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { sm += mj[i]; sm2 += mj[i] * mj[i]; sM2 += M2j[i]; }
+        for (int i = 0; i < COMBINE_CHUNK; ++i) f(__uint_as_float(v[i][0]), __uint_as_float(v[i][1]));
     }
-    sm = sum_q(sm); sm2 = sum_q(sm2); sM2 = sum_q(sM2);
+}
+__device__ __forceinline__ void stats_finish(float sm, float sm2, float sM2, int KS, float cnt, float& mean,
+                                             float& rstd) {
     mean = sm / KS;
     float between = sm2 - KS * mean * mean;
     if (between < 0.f) between = 0.f;
     const float var = (sM2 + cnt * between) / (cnt * KS);
     rstd = 1.0f / sqrtf(var + ASR_EPS);
 }
+// row statistics over all KS tiles (equal counts cnt per tile); every lane (q, bl) of every wave gets row bl's
+__device__ __forceinline__ void combine_stats(const float* st, int KS, int tid, float cnt, float& mean,
+                                              float& rstd, float* scr, int tstride = 32) {
+    const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
+    float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
+    for_tile_pairs<8>(st, KS, tstride, 4 * w + q, 16, bl, [&](float mj, float M2j) { sm += mj; sm2 += mj * mj; sM2 += M2j; });
+    sm = sum_q(sm); sm2 = sum_q(sm2); sM2 = sum_q(sM2);
+    if (q == 0) { scr[(w * 16 + bl) * 4] = sm; scr[(w * 16 + bl) * 4 + 1] = sm2; scr[(w * 16 + bl) * 4 + 2] = sM2; }
+    __syncthreads();
+    sm = 0.f; sm2 = 0.f; sM2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sm += scr[(k * 16 + bl) * 4]; sm2 += scr[(k * 16 + bl) * 4 + 1]; sM2 += scr[(k * 16 + bl) * 4 + 2]; }
+    stats_finish(sm, sm2, sM2, KS, cnt, mean, rstd);
+}
+// per-gate statistics (gate g's pairs at st + 32 g, tile stride 128): wave g combines gate g
+__device__ __forceinline__ void combine_stats4(const float* st, int KS, int tid, float cnt, f32x4& mean4,
+                                               f32x4& rstd4, float* scr) {
+    const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
+    float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
+    for_tile_pairs<32>(st + w * 32, KS, 128, q, 4, bl, [&](float mj, float M2j) { sm += mj; sm2 += mj * mj; sM2 += M2j; });
+    sm = sum_q(sm); sm2 = sum_q(sm2); sM2 = sum_q(sM2);
+    float mean, rstd;
+    stats_finish(sm, sm2, sM2, KS, cnt, mean, rstd);
+    if (q == 0) { scr[(w * 16 + bl) * 2] = mean; scr[(w * 16 + bl) * 2 + 1] = rstd; }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { mean4[g] = scr[(g * 16 + bl) * 2]; rstd4[g] = scr[(g * 16 + bl) * 2 + 1]; }
+}
 // plain sums (backward LN: sum dxh, sum dxh*xhat) over all tiles
-__device__ __forceinline__ void combine_sums(const float* st, int KS, int lane, float& s1, float& s2,
+__device__ __forceinline__ void combine_sums(const float* st, int KS, int tid, float& s1, float& s2, float* scr,
                                              int tstride = 32) {
-    const int q = lane >> 4, bl = lane & 15;
+    const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
     float a = 0.f, b = 0.f;
-    for (int s0 = q; s0 < KS; s0 += 32) {
-        float x[8], y[8];
+    for_tile_pairs<8>(st, KS, tstride, 4 * w + q, 16, bl, [&](float x, float y) { a += x; b += y; });
+    a = sum_q(a); b = sum_q(b);
+    if (q == 0) { scr[(w * 16 + bl) * 2] = a; scr[(w * 16 + bl) * 2 + 1] = b; }
+    __syncthreads();
+    s1 = 0.f; s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            x[i] = 0.f; y[i] = 0.f;
-            if (s0 + 4 * i < KS) ld_sc1_f2(st + (size_t)(s0 + 4 * i) * tstride + bl * 2, x[i], y[i]);
-        }
+    for (int k = 0; k < 4; ++k) { s1 += scr[(k * 16 + bl) * 2]; s2 += scr[(k * 16 + bl) * 2 + 1]; }
+}
+__device__ __forceinline__ void combine_sums4(const float* st, int KS, int tid, f32x4& s14, f32x4& s24, float* scr) {
+    const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
+    float a = 0.f, b = 0.f;
+    for_tile_pairs<32>(st + w * 32, KS, 128, q, 4, bl, [&](float x, float y) { a += x; b += y; });
+    a = sum_q(a); b = sum_q(b);
+    if (q == 0) { scr[(w * 16 + bl) * 2] = a; scr[(w * 16 + bl) * 2 + 1] = b; }
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { a += x[i]; b += y[i]; }
-    }
-    s1 = sum_q(a); s2 = sum_q(b);
+    for (int g = 0; g < 4; ++g) { s14[g] = scr[(g * 16 + bl) * 2]; s24[g] = scr[(g * 16 + bl) * 2 + 1]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,6 +261,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     const int s_x = own ? dt * B * 4 * N : 0, s_m = own ? dt * A.mst : 0;
     f32x4 n_x4 = *(const f32x4*)p_x;
     float n_m = *p_m;
+    STAMP_DECL
     for (int step = 0; step < T; ++step) {
         const int t = D.reverse ? T - 1 - step : step;
         const int par = step & 1;
@@ -230,6 +274,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
             n_x4 = *(const f32x4*)p_x; n_m = *p_m;
         }
         if (!group_wait(gs)) break;
+        STAMP(0);
 
         // a^T tile partials over this wave's K quarter; B operand straight from the exchange buffer
         f32x4 acc0[UT], acc1[UT];
@@ -261,6 +306,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         for (int u = 0; u < UT; ++u)
             *(f32x4*)(red + ((size_t)(u * 4 + wave) * 64 + lane) * 4) = acc0[u] + acc1[u];
         __syncthreads();
+        STAMP(1);
 
         f32x4 a4 = {0, 0, 0, 0};
         if (wave < UT) {
@@ -279,11 +325,10 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
-            if (wave < UT) {
-                float mean;
-                combine_stats(sta + (size_t)par * KS * 128, KS, lane, 16.0f, mean, rs_a, 128);
-                ah4 = (a4 - mean) * rs_a;
-            }
+            STAMP(2);
+            float mean;
+            combine_stats(sta + (size_t)par * KS * 128, KS, tid, 16.0f, mean, rs_a, red, 128);
+            ah4 = (a4 - mean) * rs_a;
         } else if (A.ln_kind) {    // gate_ln: each gate's N columns are normalised on their own;
             if (wave < UT) {       // per tile and gate: mean / M2 over the tile's 4 units
                 f32x4 mj4, M24;
@@ -299,14 +344,10 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
-            if (wave < UT) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float mean, rs;
-                    combine_stats(sta + (size_t)par * KS * 128 + g * 32, KS, lane, 4.0f, mean, rs, 128);
-                    ah4[g] = (a4[g] - mean) * rs;
-                    rs_a4[g] = rs;
-                }
+            {
+                f32x4 mean4;
+                combine_stats4(sta + (size_t)par * KS * 128, KS, tid, 4.0f, mean4, rs_a4, red);
+                ah4 = (a4 - mean4) * rs_a4;
             }
         }
         float chat_v = 0.f, rs_c = 0.f, c_new = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
@@ -324,6 +365,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
             c_new = fg * c + ig * gg;
         }
         float outcell = c_new;
+        STAMP(3);
         if (A.cell_ln) {
             if (wave < UT) {       // per-tile stats over its 4 units
                 const float mj = sum_q(c_new) * 0.25f;
@@ -333,9 +375,10 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
-            if (wave < UT) {
+            STAMP(4);
+            {
                 float mean;
-                combine_stats(stc + (size_t)par * KS * 32, KS, lane, 4.0f, mean, rs_c);
+                combine_stats(stc + (size_t)par * KS * 32, KS, tid, 4.0f, mean, rs_c, red);
                 chat_v = (c_new - mean) * rs_c;
                 outcell = ac_u * chat_v + bc_u;
             }
@@ -365,8 +408,11 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
                 }
             }
         }
+        STAMP(5);
         group_publish(gs);
+        STAMP(6);
     }
+    STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -448,6 +494,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
         n_ch = *p_ch; n_rc = *p_rc; n_c2 = *p_c2;
     };
     prefetch();
+    STAMP_DECL
 
     for (int step = 0; step < T; ++step) {
         const int st = T - 1 - step;                     // forward iteration index
@@ -470,6 +517,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
         float dr_sum = 0.f;
         if (step > 0) {
             if (!group_wait(gs)) break;
+            STAMP(0);
             const int sg = tid >> 4, f4 = tid & 15;
 #pragma unroll
             for (int u = 0; u < UT; ++u) {
@@ -495,6 +543,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
                 for (int sgi = 0; sgi < 16; ++sgi) dr_sum += rsum[((size_t)(wave * 16 + sgi) * 16 + bl) * 4 + q];
             }
         }
+        STAMP(1);
         // 2. cell / gate gradients
         const float dr_t = dre + dr_pass + dr_sum;
         const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
@@ -517,9 +566,10 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
-            if (wave < UT) {
+            STAMP(2);
+            {
                 float s1, s2;
-                combine_sums(stc + (size_t)par * KS * 32, KS, lane, s1, s2);
+                combine_sums(stc + (size_t)par * KS * 32, KS, tid, s1, s2, rsum);
                 dcn = rs_c * (dxh - s1 / N - chat_v * (s2 / N));
             }
         }
@@ -537,6 +587,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
         }
         f32x4 da4 = dg4;
         if (wave < UT && bvalid) *(f32x4*)(D.dG + row * 4 * N + col4) = dg4;
+        STAMP(3);
         if (A.ln_kind) {
             f32x4 dah = {0, 0, 0, 0};
             if (wave < UT) {
@@ -557,20 +608,20 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
-            if (wave < UT) {
+            STAMP(4);
+            {
                 if (!A.per_gate) {
                     float s1, s2;
-                    combine_sums(sta + (size_t)par * KS * 128, KS, lane, s1, s2, 128);
+                    combine_sums(sta + (size_t)par * KS * 128, KS, tid, s1, s2, rsum, 128);
                     const float m1 = s1 / (4 * N), m2 = s2 / (4 * N);
                     da4 = rs_a * (dah - m1 - ah4 * m2);
                 } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float s1, s2;
-                        combine_sums(sta + (size_t)par * KS * 128 + g * 32, KS, lane, s1, s2, 128);
-                        da4[g] = rs_a4[g] * (dah[g] - s1 / N - ah4[g] * (s2 / N));
-                    }
+                    f32x4 s14, s24;
+                    combine_sums4(sta + (size_t)par * KS * 128, KS, tid, s14, s24, rsum);
+                    da4 = rs_a4 * (dah - s14 * (1.0f / N) - ah4 * (s24 * (1.0f / N)));
                 }
+            }
+            if (wave < UT) {
                 if (bvalid) *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
             }
         }
@@ -580,6 +631,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             for (int k = 0; k < 4; ++k) dal[(size_t)wave * 256 + (q * 4 + k) * 16 + bl] = da4[k];
         }
         __syncthreads();
+        STAMP(5);
         if (step + 1 < T) {
             for (int kt = wave; kt < KT; kt += 4) {
                 f32x4 acc = {0, 0, 0, 0};
@@ -594,10 +646,13 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
                 if (dst < KS)
                     st_sc1_f4(dex_rs, (unsigned)(((((size_t)par * KS + dst) * G + j) * 64 + bl * 4) * 4), acc);
             }
+            STAMP(6);
             group_publish(gs);
+            STAMP(7);
         }
         c0v = c1v; c1v = n_c2;
     }
+    STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -629,7 +684,7 @@ extern "C" size_t asr_lstm_scan_ws_bytes(int T, int B, int N, int ndir, int back
     bytes += ng * 2 * KSP * 64 * 4;           // rex
     bytes += 5 * ng * 2 * KS * 32 * 4;        // sta (x4 for per-gate LN), stc
     if (backward) bytes += ng * 2 * (size_t)KS * KS * 64 * 4;   // dex (G <= KS)
-    return bytes + 1024;
+    return bytes + 1024 + STAMP_BYTES;
 }
 
 static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, int backward,
@@ -680,6 +735,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     A.sta = (float*)p;                             p += ng * 2 * A.KS * 128 * 4;
     A.stc = (float*)p;                             p += ng * 2 * A.KS * 32 * 4;
     A.dex = backward ? (float*)p : nullptr;
+    A.dbg = (unsigned long long*)((char*)ws + asr_lstm_scan_ws_bytes(d->T, d->B, d->N, d->ndir, backward) - STAMP_BYTES);
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
 
     size_t lds;
