@@ -15,15 +15,18 @@ pytestmark = pytest.mark.gpu
 
 def _nets():
     from asr_amd.builders import build_deep_lstm, build_deep_hyperlstm
-    from asr_amd.gating_hyper_nets import deep_projection_ln_lstm_model, deep_scaling_hyper_model
+    from asr_amd.gating_hyper_nets import (deep_projection_ln_lstm_model, deep_scaling_hyper_model,
+                                           deep_projection_hyper_model)
     yield 'lstm', lambda: build_deep_lstm(None, None, 5, 2, 8, 4, 6, 1.0, True, False, 0, device=_dev(), seed=51)
     yield 'hyper', lambda: build_deep_hyperlstm('h', None, None, 5, 2, 8, 4, 2, 6, 1.0, True, 0, device=_dev(), seed=52)
     yield 'ln_prj', lambda: deep_projection_ln_lstm_model(None, None, 5, 6, 2, 4, 8, grad_clipping=1.0, dropout=0.0,
                                                           device=_dev(), seed=53)
     yield 'scaling', lambda: deep_scaling_hyper_model(None, None, 5, 6, [4], [8], grad_clipping=1.0, device=_dev(), seed=54)
+    yield 'prjhyper', lambda: deep_projection_hyper_model(None, None, 5, 6, 2, 4, 8, grad_clipping=1.0, device=_dev(),
+                                                          seed=55)[0]
 
 
-@pytest.mark.parametrize('name', ['lstm', 'hyper', 'ln_prj', 'scaling'])
+@pytest.mark.parametrize('name', ['lstm', 'hyper', 'ln_prj', 'scaling', 'prjhyper'])
 @pytest.mark.parametrize('B,T,lengths', [(1, 1, [1]), (2, 5, [5, 0]), (33, 3, None), (17, 2, [2] * 16 + [1])])
 def test_edge_shapes(name, B, T, lengths):
     net = dict(_nets())[name]()
@@ -50,7 +53,7 @@ def test_c_abi_errors():
     assert L.asr_gemm_f32(0, 0, 4, 4, 4, 1.0, None, 4, None, 4, 0.0, None, 4, None, None) == -1
     d = _lib.HyperScanDesc()
     d.T, d.B, d.N, d.H, d.ndir = 4, 2, 10, 4, 1          # N % 4 != 0
-    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=_dev())
+    ws = torch.zeros(1 << 22, dtype=torch.uint8, device=_dev())
     assert L.asr_hyper_scan_fwd(C.byref(d), ws.data_ptr(), ws.numel(), None) == -1
     d.N = 8; d.H = 12                                     # H > N
     assert L.asr_hyper_scan_fwd(C.byref(d), ws.data_ptr(), ws.numel(), None) == -1
@@ -64,5 +67,14 @@ def test_c_abi_errors():
     for k in ('xin', 'wpack', 'r_out', 'cst'):
         setattr(ld.dir[0], k, x.data_ptr())
     assert L.asr_lstm_scan_fwd(C.byref(ld), ws.data_ptr(), 16, None) == -3
+    pd = _lib.PrjHyperDesc()
+    pd.T, pd.B, pd.N, pd.F, pd.ndir, pd.Btot = 4, 17, 8, 4, 1, 17     # more than 16 rows in one call
+    pd.mask = m.data_ptr()
+    assert L.asr_prjhyper_fwd(C.byref(pd), ws.data_ptr(), ws.numel(), None) == -1
+    pd.B = 2; pd.F = 6                                                # F % 4 != 0
+    assert L.asr_prjhyper_fwd(C.byref(pd), ws.data_ptr(), ws.numel(), None) == -1
+    pd.F = 4
+    assert L.asr_prjhyper_fwd(C.byref(pd), ws.data_ptr(), 64, None) == -3
+    assert L.asr_prjhyper_fwd(C.byref(pd), ws.data_ptr(), ws.numel(), None) == -1   # null tensors
     assert L.asr_opt_step(9, ws.data_ptr(), ws.data_ptr(), None, None, 4, 0.1, 0.0, 0.0, 0.0, None, None) == -1
     assert L.asr_opt_step(1, ws.data_ptr(), ws.data_ptr(), None, None, 4, 0.1, 0.9, 0.0, 0.0, None, None) == -1
