@@ -114,19 +114,23 @@ extern "C" int asr_lstm_pack_w(const float* W, int N, int mode, float* out, hipS
 // ALL FOUR WAVES of the workgroup take part (call it outside any `wave < UT` branch): wave w, lane (q, bl)
 // sums tiles 16 i + 4 w + q of batch row bl, the four partial sums meet in LDS (`scr`, 256 floats, free at
 // the call sites; the caller's next barrier precedes its next write).
-typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
 template <int COMBINE_CHUNK, typename F>
 __device__ __forceinline__ void for_tile_pairs(const float* st, int KS, int tstride, int first, int stride, int bl,
-                                               F&& f) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc_(st, (unsigned)(((KS - 1) * tstride + 32) * 4));
-    const unsigned voff = (unsigned)((first * tstride + bl * 2) * 4);
+                                               int sub, F&& f) {
+    // `st` and the descriptor are workgroup-uniform (a per-wave base would make hipcc wrap every load in a
+    // readfirstlane loop); `sub` = float offset of this wave's 32-float block inside a tile's tstride floats
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc_(st, (unsigned)(KS * tstride * 4));
+    // 16-byte loads (the pairs of batch rows bl & ~1 and bl | 1), the lane keeps its own half: the sc1 hand-off
+    // behind replicated arrival counters is measured for 4- and 16-byte loads, not 8-byte ones
+    // (MI355X_MICROARCH.md, table under 'Valid forms')
+    const unsigned voff = (unsigned)((first * tstride + sub + (bl & ~1) * 2) * 4);
+    const bool hi = bl & 1;
     for (int s0 = 0; s0 < KS; s0 += stride * COMBINE_CHUNK) {
-        u32x2_ v[COMBINE_CHUNK];
+        f32x4 v[COMBINE_CHUNK];
 #pragma unroll
-        for (int i = 0; i < COMBINE_CHUNK; ++i)
-            v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)((s0 + stride * i) * tstride * 4), 16);
+        for (int i = 0; i < COMBINE_CHUNK; ++i) v[i] = ldb_sc1_f4(rs, voff, (unsigned)((s0 + stride * i) * tstride * 4));
 #pragma unroll
-        for (int i = 0; i < COMBINE_CHUNK; ++i) f(__uint_as_float(v[i][0]), __uint_as_float(v[i][1]));
+        for (int i = 0; i < COMBINE_CHUNK; ++i) f(hi ? v[i][2] : v[i][0], hi ? v[i][3] : v[i][1]);
     }
 }
 __device__ __forceinline__ void stats_finish(float sm, float sm2, float sM2, int KS, float cnt, float& mean,
@@ -142,7 +146,7 @@ __device__ __forceinline__ void combine_stats(const float* st, int KS, int tid, 
                                               float& rstd, float* scr, int tstride = 32) {
     const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
     float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
-    for_tile_pairs<8>(st, KS, tstride, 4 * w + q, 16, bl, [&](float mj, float M2j) { sm += mj; sm2 += mj * mj; sM2 += M2j; });
+    for_tile_pairs<8>(st, KS, tstride, 4 * w + q, 16, bl, 0, [&](float mj, float M2j) { sm += mj; sm2 += mj * mj; sM2 += M2j; });
     sm = sum_q(sm); sm2 = sum_q(sm2); sM2 = sum_q(sM2);
     if (q == 0) { scr[(w * 16 + bl) * 4] = sm; scr[(w * 16 + bl) * 4 + 1] = sm2; scr[(w * 16 + bl) * 4 + 2] = sM2; }
     __syncthreads();
@@ -156,7 +160,7 @@ __device__ __forceinline__ void combine_stats4(const float* st, int KS, int tid,
                                                f32x4& rstd4, float* scr) {
     const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
     float sm = 0.f, sm2 = 0.f, sM2 = 0.f;
-    for_tile_pairs<32>(st + w * 32, KS, 128, q, 4, bl, [&](float mj, float M2j) { sm += mj; sm2 += mj * mj; sM2 += M2j; });
+    for_tile_pairs<32>(st, KS, 128, q, 4, bl, w * 32, [&](float mj, float M2j) { sm += mj; sm2 += mj * mj; sM2 += M2j; });
     sm = sum_q(sm); sm2 = sum_q(sm2); sM2 = sum_q(sM2);
     float mean, rstd;
     stats_finish(sm, sm2, sM2, KS, cnt, mean, rstd);
@@ -170,7 +174,7 @@ __device__ __forceinline__ void combine_sums(const float* st, int KS, int tid, f
                                              int tstride = 32) {
     const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
     float a = 0.f, b = 0.f;
-    for_tile_pairs<8>(st, KS, tstride, 4 * w + q, 16, bl, [&](float x, float y) { a += x; b += y; });
+    for_tile_pairs<8>(st, KS, tstride, 4 * w + q, 16, bl, 0, [&](float x, float y) { a += x; b += y; });
     a = sum_q(a); b = sum_q(b);
     if (q == 0) { scr[(w * 16 + bl) * 2] = a; scr[(w * 16 + bl) * 2 + 1] = b; }
     __syncthreads();
@@ -181,7 +185,7 @@ __device__ __forceinline__ void combine_sums(const float* st, int KS, int tid, f
 __device__ __forceinline__ void combine_sums4(const float* st, int KS, int tid, f32x4& s14, f32x4& s24, float* scr) {
     const int w = tid >> 6, q = (tid >> 4) & 3, bl = tid & 15;
     float a = 0.f, b = 0.f;
-    for_tile_pairs<32>(st + w * 32, KS, 128, q, 4, bl, [&](float x, float y) { a += x; b += y; });
+    for_tile_pairs<32>(st, KS, 128, q, 4, bl, w * 32, [&](float x, float y) { a += x; b += y; });
     a = sum_q(a); b = sum_q(b);
     if (q == 0) { scr[(w * 16 + bl) * 2] = a; scr[(w * 16 + bl) * 2 + 1] = b; }
     __syncthreads();
@@ -245,6 +249,12 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         }
     float ac_u = 1.f, bc_u = 0.f;
     if (A.cell_ln) { ac_u = D.alpha_c[unit]; bc_u = D.beta_c[unit]; }
+    // LN gain / shift of this lane's 4 gate columns: loop-invariant, read once (per sample when ln_kind == 2)
+    f32x4 al4 = {1.f, 1.f, 1.f, 1.f}, be4 = {0.f, 0.f, 0.f, 0.f};
+    if (A.ln_kind && wave < UT) {
+        al4 = *(const f32x4*)(D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4);
+        if (D.beta_hid) be4 = *(const f32x4*)(D.beta_hid + col4);
+    }
     group_publish(gs);
 
     const int s4_per_wave = KSP / 16;                    // groups of 4 MFMA k-steps per wave
@@ -261,6 +271,21 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     const int s_x = own ? dt * B * 4 * N : 0, s_m = own ? dt * A.mst : 0;
     f32x4 n_x4 = *(const f32x4*)p_x;
     float n_m = *p_m;
+    // the saves walk per-lane pointers too: addresses formed from the descriptor inside the loop reload its
+    // fields through scalar loads that are waited for one by one
+    const size_t rw0 = (size_t)t0 * B + bq;
+    const bool sv_ln = A.ln_kind && D.ahat, sv_cl = A.cell_ln && D.chat;
+    const int rsw = A.per_gate ? 4 : 1;
+    float* q_r = D.r_out + rw0 * D.ld_r + unit;
+    float* q_c = D.cst + rw0 * N + unit;
+    float* q_g = D.gates ? D.gates + rw0 * 4 * N + col4 : nullptr;
+    float* q_ah = sv_ln ? D.ahat + rw0 * 4 * N + col4 : nullptr;
+    float* q_ra = sv_ln ? D.rs_a + rw0 * rsw : nullptr;
+    float* q_ch = sv_cl ? D.chat + rw0 * N + unit : nullptr;
+    float* q_rc = sv_cl ? D.rs_c + rw0 : nullptr;
+    const int z_r = dt * B * D.ld_r, z_c = dt * B * N, z_g = q_g ? dt * B * 4 * N : 0, z_ah = sv_ln ? dt * B * 4 * N : 0;
+    const int z_ra = sv_ln ? dt * B * rsw : 0, z_ch = sv_cl ? dt * B * N : 0, z_rc = sv_cl ? dt * B : 0;
+    const bool lead = tile == 0 && q == 0;
     STAMP_DECL
     for (int step = 0; step < T; ++step) {
         const int t = D.reverse ? T - 1 - step : step;
@@ -354,10 +379,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
         if (wave < UT) {
             f32x4 pre;
             if (A.ln_kind) {
-                const float* al = D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4;
-                const f32x4 al4 = *(const f32x4*)al;
-                pre = x4 + al4 * ah4;
-                if (D.beta_hid) pre += *(const f32x4*)(D.beta_hid + col4);
+                pre = x4 + al4 * ah4 + be4;
             } else {
                 pre = x4 + a4;
             }
@@ -392,21 +414,22 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
                     st_sc1_f4(rex_rs, (unsigned)((((size_t)(par ^ 1) * KSP + tile) * 64 + bl * 4) * 4), f32x4{r, r1, r2, r3});
             }
             if (bvalid) {
-                D.r_out[row * D.ld_r + unit] = r;
-                D.cst[row * N + unit] = c;
-                if (D.gates) *(f32x4*)(D.gates + row * 4 * N + col4) = f32x4{ig, fg, gg, og};
-                if (A.ln_kind && D.ahat) {
-                    *(f32x4*)(D.ahat + row * 4 * N + col4) = ah4;
-                    if (tile == 0 && q == 0) {
-                        if (A.per_gate) *(f32x4*)(D.rs_a + row * 4) = rs_a4;
-                        else D.rs_a[row] = rs_a;
+                *q_r = r;
+                *q_c = c;
+                if (q_g) *(f32x4*)q_g = f32x4{ig, fg, gg, og};
+                if (q_ah) {
+                    *(f32x4*)q_ah = ah4;
+                    if (lead) {
+                        if (A.per_gate) *(f32x4*)q_ra = rs_a4;
+                        else *q_ra = rs_a;
                     }
                 }
-                if (A.cell_ln && D.chat) {
-                    D.chat[row * N + unit] = chat_v;
-                    if (tile == 0 && q == 0) D.rs_c[row] = rs_c;
+                if (q_ch) {
+                    *q_ch = chat_v;
+                    if (lead) *q_rc = rs_c;
                 }
             }
+            q_r += z_r; q_c += z_c; q_g += z_g; q_ah += z_ah; q_ra += z_ra; q_ch += z_ch; q_rc += z_rc;
         }
         STAMP(5);
         group_publish(gs);
@@ -456,6 +479,9 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
     float ac_u = 1.f, bc_u = 0.f;
     if (A.cell_ln) { ac_u = D.alpha_c[unit]; bc_u = D.beta_c[unit]; }
     float dc = 0.f, dr_pass = 0.f;
+    f32x4 al4 = {1.f, 1.f, 1.f, 1.f};                  // LN gain of this lane's 4 gate columns (loop-invariant)
+    if (A.ln_kind && wave < UT)
+        al4 = *(const f32x4*)(D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4);
     __syncthreads();
 
     // Saved tensors of a step are loaded one step ahead through walking per-lane pointers, branch-free
@@ -494,6 +520,11 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
         n_ch = *p_ch; n_rc = *p_rc; n_c2 = *p_c2;
     };
     prefetch();
+    // gradient saves through walking per-lane pointers as well (see the forward kernel)
+    float* q_dg = D.dG + r00 * 4 * N + col4;
+    float* q_da = (A.ln_kind && D.dA) ? D.dA + r00 * 4 * N + col4 : nullptr;
+    float* q_do = (A.cell_ln && D.dOut) ? D.dOut + r00 * N + unit : nullptr;
+    const int z_dg = dt * B * 4 * N, z_da = q_da ? dt * B * 4 * N : 0, z_do = q_do ? dt * B * N : 0;
     STAMP_DECL
 
     for (int step = 0; step < T; ++step) {
@@ -562,7 +593,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             if (wave < UT) {
                 const float s1 = sum_q(dxh), s2 = sum_q(dxh * chat_v);
                 if (q == 0) st_sc1_f2(stc + ((size_t)par * KS + tile) * 32 + bl * 2, s1, s2);
-                if (bvalid && D.dOut) D.dOut[row * N + unit] = dout;
+                if (bvalid && q_do) *q_do = dout;
             }
             group_publish(gs);
             if (!group_wait(gs)) break;
@@ -586,13 +617,12 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             dr_pass = dr_t;
         }
         f32x4 da4 = dg4;
-        if (wave < UT && bvalid) *(f32x4*)(D.dG + row * 4 * N + col4) = dg4;
+        if (wave < UT && bvalid) *(f32x4*)q_dg = dg4;
         STAMP(3);
         if (A.ln_kind) {
             f32x4 dah = {0, 0, 0, 0};
             if (wave < UT) {
-                const float* al = D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4;
-                dah = dg4 * (*(const f32x4*)al);
+                dah = dg4 * al4;
                 if (!A.per_gate) {
                     const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
                     const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
@@ -621,9 +651,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
                     da4 = rs_a4 * (dah - s14 * (1.0f / N) - ah4 * (s24 * (1.0f / N)));
                 }
             }
-            if (wave < UT) {
-                if (bvalid) *(f32x4*)(D.dA + row * 4 * N + col4) = da4;
-            }
+            if (wave < UT && bvalid && q_da) *(f32x4*)q_da = da4;
         }
         // 3. partial dr_{prev}: B operand needs da[b][col 4e+(l>>4)] -> go through LDS
         if (wave < UT) {
@@ -651,6 +679,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             STAMP(7);
         }
         c0v = c1v; c1v = n_c2;
+        q_dg += z_dg; q_da += z_da; q_do += z_do;
     }
     STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
