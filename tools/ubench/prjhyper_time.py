@@ -1,9 +1,9 @@
 """Time one training step (fwd + BPTT) of deep_projection_hyper_model at the reference script's defaults
 (3 layers, 512 units, 256 factors, B=16, WSJ-shaped lengths) on cuda:0.  Prints frames/s."""
-import sys, time
+import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from asr_amd import gating_hyper_nets as G, workloads
 
 dev = 'cuda:0'
