@@ -223,7 +223,6 @@ struct PrjArgs {
     int t[2], tp[2];            // time index of this step / of the previous forward step (-1: none)
     float* tg;                  // (ndir,B,4N) recurrent part of the inner gates
     float *g_c[2], *g_r[2];     // (ndir,B,N) carried d cell / d r state: [0] inner, [1] outer
-    float* g_h;                 // (ndir,B,2F) d hid from the step processed before (the future)
 };
 
 __device__ __forceinline__ float block_sum(float v, float* sm) {
@@ -396,16 +395,6 @@ static void prj_cell_bwd_launch(const PrjArgs& A, int ndir, hipStream_t st) {
     else hipLaunchKernelGGL((prj_cell_bwd_kernel<OUTER, PRJ_MAXU>), grid, block, 0, st, A);
 }
 
-// dh[t] = dhid[t] + g_h  (both halves), for both directions
-__global__ void prj_dh_kernel(PrjArgs A) {
-    const int dir = blockIdx.y;
-    const PrjDir& D = A.d[dir];
-    const int n2 = A.B * 2 * A.F;
-    const size_t base = ((size_t)A.t[dir] * A.Btot + A.b0) * 2 * A.F;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x)
-        D.dh[base + i] = D.dhid[base + i] + A.g_h[(size_t)dir * n2 + i];
-}
-
 struct asr_prjhyper_desc {      // mirrored in include/asr_amd.h
     int T, B, N, F, ndir;
     int b0, Btot;               // rows [b0, b0+B) of Btot; B <= 16 per call
@@ -446,7 +435,7 @@ static int prj_args(const asr_prjhyper_desc* d, void* ws, hipStream_t st, PrjHos
     const size_t bn = (size_t)d->ndir * d->B * d->N;
     A.tg = p; p += 4 * bn;
     A.g_c[0] = p; p += bn; A.g_c[1] = p; p += bn; A.g_r[0] = p; p += bn; A.g_r[1] = p; p += bn;
-    A.g_h = p; p += (size_t)d->ndir * d->B * 2 * d->F;
+    p += (size_t)d->ndir * d->B * 2 * d->F;             // (spare)
     H.zeros = p; p += (size_t)d->B * 2 * d->F;
     H.part = p; p += SK_PART_FLOATS;
     H.tickets = (unsigned*)p;
@@ -542,9 +531,17 @@ extern "C" int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
     PrjArgs& A = H.A;
     const int T = d->T, B = d->B, N = d->N, F = d->F;
     // carried gradients start at zero (tg is not used backward)
-    if (hipMemsetAsync(A.g_c[0], 0, ((size_t)4 * d->ndir * B * N + (size_t)d->ndir * B * 2 * F) * sizeof(float), st) !=
+    if (hipMemsetAsync(A.g_c[0], 0, (size_t)4 * d->ndir * B * N * sizeof(float), st) !=
         hipSuccess)
         return ASR_ERR_LAUNCH;
+    // dh starts as dhid (rows of this chunk, every t); each step adds its recurrent part to dh of the step before
+    for (int k = 0; k < d->ndir; ++k) {
+        const PrjDir& D = d->dir[k];
+        if (hipMemcpy2DAsync(D.dh + (size_t)d->b0 * 2 * F, (size_t)d->Btot * 2 * F * sizeof(float),
+                             D.dhid + (size_t)d->b0 * 2 * F, (size_t)d->Btot * 2 * F * sizeof(float),
+                             (size_t)B * 2 * F * sizeof(float), T, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return ASR_ERR_LAUNCH;
+    }
     for (int step = T - 1; step >= 0; --step) {
         prj_times(d, A, step);
         const float *dh_i[2], *dh_o[2], *dsc[2], *dii[2], *da[2];
@@ -557,11 +554,9 @@ extern "C" int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
             dh_iw[k] = D.dh + row0 * 2 * F; dh_i[k] = dh_iw[k]; dh_o[k] = dh_iw[k] + F;
             dsc[k] = D.dsc + row0 * 12 * N; dii[k] = D.dii + row0 * 4 * N; da[k] = D.da + row0 * 4 * N;
             gr0[k] = A.g_r[0] + (size_t)kk * B * N; gr1[k] = A.g_r[1] + (size_t)kk * B * N;
-            gh[k] = A.g_h + (size_t)kk * B * 2 * F; gh_o[k] = gh[k] + F;
+            gh[k] = D.dh + ((size_t)(A.tp[kk] < 0 ? A.t[kk] : A.tp[kk]) * d->Btot + d->b0) * 2 * F; gh_o[k] = gh[k] + F;
             Wio[k] = D.Wio; Wip[k] = D.Wi_p; Sm[k] = D.S; Woo[k] = D.Wo_o; Wop[k] = D.Wo_p;
         }
-        hipLaunchKernelGGL(prj_dh_kernel, dim3(4, d->ndir), dim3(256), 0, st, A);
-        ASR_CHECK_LAUNCH();
         // d r_out (total) += d outer_hid . W_outer_prj^T
         if ((rc = prj_mm(H, true, dh_o, 2 * F, Wop, F, nullptr, gr1, N, F, N, 1))) return rc;
         prj_cell_bwd_launch<1>(A, d->ndir, st);
@@ -571,9 +566,11 @@ extern "C" int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
         if ((rc = prj_mm(H, true, dh_i, 2 * F, Wip, F, nullptr, gr0, N, F, N, 1))) return rc;
         prj_cell_bwd_launch<0>(A, d->ndir, st);
         ASR_CHECK_LAUNCH();
-        // d hid_{t-1} = d inner gates . Wio^T ; its outer half += da . Wo_o^T
-        if ((rc = prj_mm(H, true, dii, 4 * N, Wio, 4 * N, nullptr, gh, 2 * F, 4 * N, 2 * F, 0))) return rc;
-        if ((rc = prj_mm(H, true, da, 4 * N, Woo, 4 * N, nullptr, gh_o, 2 * F, 4 * N, F, 1))) return rc;
+        // d hid_{t-1} (already holding dhid_{t-1}) += d inner gates . Wio^T ; its outer half += da . Wo_o^T
+        if (step > 0) {
+            if ((rc = prj_mm(H, true, dii, 4 * N, Wio, 4 * N, nullptr, gh, 2 * F, 4 * N, 2 * F, 1))) return rc;
+            if ((rc = prj_mm(H, true, da, 4 * N, Woo, 4 * N, nullptr, gh_o, 2 * F, 4 * N, F, 1))) return rc;
+        }
     }
     return ASR_OK;
 }
