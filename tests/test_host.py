@@ -51,6 +51,8 @@ int main(void) {
          sizeof(asr_hyper_scan_desc));
   printf("%zu %zu %zu %zu\\n", offsetof(asr_lstm_scan_desc, dir), offsetof(asr_lstm_dir, dOut),
          offsetof(asr_hyper_scan_desc, dir), offsetof(asr_hyper_dir, dD));
+  printf("%zu %zu %zu %zu\\n", sizeof(asr_prjhyper_dir), sizeof(asr_prjhyper_desc), offsetof(asr_prjhyper_desc, dir),
+         offsetof(asr_prjhyper_dir, douto));
   return 0;
 }''')
     exe = tmp_path / 'layout'
@@ -60,7 +62,9 @@ int main(void) {
     got = [int(v) for v in out]
     want = [C.sizeof(_lib.LstmDir), C.sizeof(_lib.LstmScanDesc), C.sizeof(_lib.HyperDir),
             C.sizeof(_lib.HyperScanDesc), _lib.LstmScanDesc.dir.offset, _lib.LstmDir.dOut.offset,
-            _lib.HyperScanDesc.dir.offset, _lib.HyperDir.dD.offset]
+            _lib.HyperScanDesc.dir.offset, _lib.HyperDir.dD.offset,
+            C.sizeof(_lib.PrjHyperDir), C.sizeof(_lib.PrjHyperDesc), _lib.PrjHyperDesc.dir.offset,
+            _lib.PrjHyperDir.douto.offset]
     assert got == want
 
 
