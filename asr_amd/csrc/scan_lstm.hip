@@ -439,6 +439,250 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, cell-LN variants with one exchange fewer per step (UT = 1, N <= 512).  Instead of r_t the
+// workgroups all-gather (c_new, o) of their units; every workgroup then forms the cell-LN statistics of its
+// 16 batch rows over all N units itself and r_t = o * tanh(alpha_c * chat + beta_c) for all units, in the
+// registers that feed the MFMA B operand (each lane keeps r_{t-1} of its 32 (unit, row) pairs for the masked
+// carry).  The owner's saves that need the statistics (r_out, chat, rs_c of step t) happen at the top of
+// step t+1; one extra wait after the loop flushes the last step.  Same arithmetic as the generic kernel
+// except the order of the sums inside the cell-LN statistics.
+// ------------------------------------------------------------------------------------------------
+// tanh with the hardware reciprocal (1 ulp) instead of an IEEE division: 32 of them per lane and step sit on the
+// critical path of the kernel below; the saved r_out uses the same form, so state and saves agree bit for bit
+__device__ __forceinline__ float tanh_rcp_(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+__global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                   // [KSP/4][64][4]
+    float* red = Wl + (size_t)A.KSP * 64;               // [4 waves][64][4]
+    int* flag = (int*)(red + 4 * 256);
+    float* scr = (float*)flag + 16;                     // [2][4 waves][16 rows] statistics partials
+
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
+    const int grp = chunk * A.ndir + dir;
+    const LstmDir& D = A.d[dir];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, bl = lane & 15;
+    const int b = chunk * 16 + bl;
+    const bool bvalid = b < A.B;
+    const int N = A.N, KS = A.KS, KSP = A.KSP, T = A.T, B = A.B;
+
+    GroupSync gs;
+    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
+    {
+        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * KSP * 64);
+        f32x4* dst = (f32x4*)Wl;
+        for (int i = tid; i < KSP * 16; i += 256) dst[i] = src[i];
+    }
+    // exchange layout [parity][tile][c | o][batch][unit]
+    float* rex = A.rex + (size_t)grp * 4 * KSP * 64;
+    float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 128 : nullptr;
+    const __amdgpu_buffer_rsrc_t rex_rs = make_rsrc_(rex, (unsigned)(4 * KSP * 64 * 4));
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned ex_voff = (unsigned)((q * 128 + bl * 4) * 4);
+    const int s4pw = KSP / 16;                           // <= 8: groups of 4 MFMA k-steps per wave
+
+    const bool own = wv == 0;
+    const int tile = j, unit = tile * 4 + q, col4 = unit * 4;
+    float c = 0.f, r = 0.f;
+    if (own) {
+        if (bvalid && D.c0) c = D.c0[(size_t)b * N + unit];
+        if (bvalid && D.r0) r = D.r0[(size_t)b * N + unit];
+        const float r1 = __shfl(r, bl + 16), r2 = __shfl(r, bl + 32), r3 = __shfl(r, bl + 48);
+        if (q == 0) st_sc1_f4(rex_rs, (unsigned)(((size_t)tile * 128 + bl * 4) * 4), f32x4{r, r1, r2, r3});   // r_{-1} in the c slot
+    }
+    const float ac_u = D.alpha_c[unit], bc_u = D.beta_c[unit];
+    f32x4 al4 = {1.f, 1.f, 1.f, 1.f}, be4 = {0.f, 0.f, 0.f, 0.f};
+    if (A.ln_kind && own) {
+        al4 = *(const f32x4*)(D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4);
+        if (D.beta_hid) be4 = *(const f32x4*)(D.beta_hid + col4);
+    }
+    // cell-LN gain / shift of the 32 units this lane feeds to the MFMA: unit 4 * (4 * (wv * s4pw + i) + q) + e
+    f32x4 acv[8], bcv[8], rp[8];
+    bool tv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tl = 4 * (wv * s4pw + i) + q;
+        tv[i] = i < s4pw && tl < KS;
+        const int tq = tv[i] ? tl : 0;
+        acv[i] = *(const f32x4*)(D.alpha_c + tq * 4);
+        bcv[i] = *(const f32x4*)(D.beta_c + tq * 4);
+        rp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    group_publish(gs);
+
+    const int bq = bvalid ? b : (B - 1);
+    const float* const dummy = D.wpack;
+    const int dt = D.reverse ? -1 : 1;
+    const int t0 = D.reverse ? T - 1 : 0;
+    const float* p_x = own ? D.xin + ((size_t)t0 * B + bq) * 4 * N + col4 : dummy;
+    const float* p_m = A.mask + (size_t)bq * A.msb + (size_t)t0 * A.mst;      // every lane: row bl's mask
+    const int s_x = own ? dt * B * 4 * N : 0, s_m = dt * A.mst;
+    f32x4 n_x4 = *(const f32x4*)p_x;
+    float n_m = *p_m;
+    const size_t rw0 = (size_t)t0 * B + bq;
+    const bool sv_ln = A.ln_kind && D.ahat, sv_cl = D.chat != nullptr;
+    const int rsw = A.per_gate ? 4 : 1;
+    float* q_r = D.r_out + rw0 * D.ld_r + unit;
+    float* q_c = D.cst + rw0 * N + unit;
+    float* q_g = D.gates ? D.gates + rw0 * 4 * N + col4 : nullptr;
+    float* q_ah = sv_ln ? D.ahat + rw0 * 4 * N + col4 : nullptr;
+    float* q_ra = sv_ln ? D.rs_a + rw0 * rsw : nullptr;
+    float* q_ch = sv_cl ? D.chat + rw0 * N + unit : nullptr;
+    float* q_rc = sv_cl ? D.rs_c + rw0 : nullptr;
+    const int z_r = dt * B * D.ld_r, z_c = dt * B * N, z_g = q_g ? dt * B * 4 * N : 0, z_ah = sv_ln ? dt * B * 4 * N : 0;
+    const int z_ra = sv_ln ? dt * B * rsw : 0, z_ch = sv_cl ? dt * B * N : 0, z_rc = sv_cl ? dt * B : 0;
+    const bool lead = tile == 0 && q == 0;
+    float m_prev = 0.f, c_sv = 0.f, o_sv = 0.f;         // the step whose r is still to be formed
+    for (int step = 0; step <= T; ++step) {
+        const int par = step & 1;
+        const f32x4 x4 = n_x4;
+        const float m = bvalid ? n_m : 0.f;
+        {
+            const bool go = step + 1 < T;
+            p_x += go ? s_x : 0; p_m += go ? s_m : 0;
+            n_x4 = *(const f32x4*)p_x; n_m = *p_m;
+        }
+        if (!group_wait(gs)) break;
+        f32x4 cv[8], ov[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned so = (unsigned)(par * KSP * 512) + (unsigned)(wv * s4pw + i) * 2048u;
+            cv[i] = ldb_sc1_f4(rex_rs, ex_voff, so);
+            ov[i] = ldb_sc1_f4(rex_rs, ex_voff + 256u, so);
+        }
+        if (step == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rp[i] = tv[i] ? cv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s1 += tv[i] ? (cv[i][0] + cv[i][1]) + (cv[i][2] + cv[i][3]) : 0.f;
+            s1 = sum_q(s1);
+            if (q == 0) scr[wave * 16 + bl] = s1;
+            __syncthreads();
+            const float mean = ((scr[bl] + scr[16 + bl]) + (scr[32 + bl] + scr[48 + bl])) / N;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 dl = cv[i] - mean;
+                s2 += tv[i] ? (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]) : 0.f;
+            }
+            s2 = sum_q(s2);
+            if (q == 0) scr[64 + wave * 16 + bl] = s2;
+            __syncthreads();
+            const float rstd = 1.0f / sqrtf(((scr[64 + bl] + scr[80 + bl]) + (scr[96 + bl] + scr[112 + bl])) / N + ASR_EPS);
+            const bool onp = m_prev != 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float rn = ov[i][e] * tanh_rcp_(acv[i][e] * ((cv[i][e] - mean) * rstd) + bcv[i][e]);
+                    rp[i][e] = (onp && tv[i]) ? rn : rp[i][e];
+                }
+            }
+            if (own) {                                   // the saves of the step before that needed the statistics
+                const float chat_v = (c_sv - mean) * rstd;
+                const float r_new = o_sv * tanh_rcp_(ac_u * chat_v + bc_u);
+                if (onp) r = r_new;
+                if (bvalid) {
+                    *q_r = r;
+                    if (q_ch) {
+                        *q_ch = chat_v;
+                        if (lead) *q_rc = rstd;
+                    }
+                }
+                q_r += z_r; q_ch += z_ch; q_rc += z_rc;
+            }
+        }
+        if (step == T) break;
+
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int g4 = 0; g4 < 8; ++g4) {
+            if (g4 < s4pw) {
+                const f32x4 av = *(const f32x4*)(Wl + (((size_t)(wave * s4pw + g4)) * 64 + lane) * 4);
+                acc0 = mfma4(av[0], rp[g4][0], acc0);
+                acc1 = mfma4(av[1], rp[g4][1], acc1);
+                acc0 = mfma4(av[2], rp[g4][2], acc0);
+                acc1 = mfma4(av[3], rp[g4][3], acc1);
+            }
+        }
+        *(f32x4*)(red + ((size_t)wave * 64 + lane) * 4) = acc0 + acc1;
+        __syncthreads();
+        f32x4 a4 = {0, 0, 0, 0};
+        if (own) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)w * 64 + lane) * 4);
+        }
+        float rs_a = 0.f;
+        f32x4 rs_a4 = {0, 0, 0, 0}, ah4 = {0, 0, 0, 0};
+        if (A.ln_kind && !A.per_gate) {
+            if (own) {
+                const float mj = sum_q(a4[0] + a4[1] + a4[2] + a4[3]) * (1.0f / 16.0f);
+                f32x4 dlt = a4 - mj;
+                const float M2 = sum_q(dlt[0] * dlt[0] + dlt[1] * dlt[1] + dlt[2] * dlt[2] + dlt[3] * dlt[3]);
+                if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 128 + bl * 2, mj, M2);
+            }
+            group_publish(gs);
+            if (!group_wait(gs)) break;
+            float mean;
+            combine_stats(sta + (size_t)par * KS * 128, KS, tid, 16.0f, mean, rs_a, red, 128);
+            ah4 = (a4 - mean) * rs_a;
+        } else if (A.ln_kind) {
+            if (own) {
+                f32x4 mj4, M24;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    mj4[g] = sum_q(a4[g]) * 0.25f;
+                    const float dl = a4[g] - mj4[g];
+                    M24[g] = sum_q(dl * dl);
+                }
+                const float mjq = q == 0 ? mj4[0] : q == 1 ? mj4[1] : q == 2 ? mj4[2] : mj4[3];
+                const float M2q = q == 0 ? M24[0] : q == 1 ? M24[1] : q == 2 ? M24[2] : M24[3];
+                st_sc1_f2(sta + (((size_t)par * KS + tile) * 4 + q) * 32 + bl * 2, mjq, M2q);
+            }
+            group_publish(gs);
+            if (!group_wait(gs)) break;
+            f32x4 mean4;
+            combine_stats4(sta + (size_t)par * KS * 128, KS, tid, 4.0f, mean4, rs_a4, red);
+            ah4 = (a4 - mean4) * rs_a4;
+        }
+        if (own) {
+            const f32x4 pre = A.ln_kind ? x4 + al4 * ah4 + be4 : x4 + a4;
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            const float c_new = fg * c + ig * gg;
+            if (m != 0.f) c = c_new;
+            c_sv = c_new; o_sv = og;
+            {
+                const float c1 = __shfl(c_new, bl + 16), c2 = __shfl(c_new, bl + 32), c3 = __shfl(c_new, bl + 48);
+                const float o1 = __shfl(og, bl + 16), o2 = __shfl(og, bl + 32), o3 = __shfl(og, bl + 48);
+                if (q == 0) {
+                    const unsigned base = (unsigned)((((size_t)(par ^ 1) * KSP + tile) * 128 + bl * 4) * 4);
+                    st_sc1_f4(rex_rs, base, f32x4{c_new, c1, c2, c3});
+                    st_sc1_f4(rex_rs, base + 256u, f32x4{og, o1, o2, o3});
+                }
+            }
+            if (bvalid) {
+                *q_c = c;
+                if (q_g) *(f32x4*)q_g = f32x4{ig, fg, gg, og};
+                if (q_ah) {
+                    *(f32x4*)q_ah = ah4;
+                    if (lead) {
+                        if (A.per_gate) *(f32x4*)q_ra = rs_a4;
+                        else *q_ra = rs_a;
+                    }
+                }
+            }
+            q_c += z_c; q_g += z_g; q_ah += z_ah; q_ra += z_ra;
+        }
+        m_prev = m;
+        group_publish(gs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward (BPTT).  Walks the forward iteration order in reverse.  Per step and workgroup:
 //   1. sum the partial dr_{t} contributions every workgroup published in the previous step
 //   2. cell / gate gradients for its units (+ LN backward with two small stat exchanges)
@@ -710,7 +954,7 @@ extern "C" size_t asr_lstm_scan_ws_bytes(int T, int B, int N, int ndir, int back
     const int nchunk = (B + 15) / 16;
     const size_t ng = (size_t)ndir * nchunk;
     size_t bytes = ng * SYNC_STRIDE * 4;
-    bytes += ng * 2 * KSP * 64 * 4;           // rex
+    bytes += ng * 4 * KSP * 64 * 4;           // rex (r, or (c, o) for lstm_scan_fwd_cln_kernel)
     bytes += 5 * ng * 2 * KS * 32 * 4;        // sta (x4 for per-gate LN), stc
     if (backward) bytes += ng * 2 * (size_t)KS * KS * 64 * 4;   // dex (G <= KS)
     return bytes + 1024 + STAMP_BYTES;
@@ -760,7 +1004,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     char* p = (char*)ws;
     const size_t ng = (size_t)d->ndir * nchunk_total;
     A.sync = (unsigned*)p;                         p += ng * SYNC_STRIDE * 4;
-    A.rex = (float*)p;                             p += ng * 2 * A.KSP * 64 * 4;
+    A.rex = (float*)p;                             p += ng * 4 * A.KSP * 64 * 4;
     A.sta = (float*)p;                             p += ng * 2 * A.KS * 128 * 4;
     A.stc = (float*)p;                             p += ng * 2 * A.KS * 32 * 4;
     A.dex = backward ? (float*)p : nullptr;
@@ -768,7 +1012,9 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
 
     size_t lds;
-    if (!backward) lds = ((size_t)UT * A.KSP * 64 + UT * 4 * 256) * 4 + 64;
+    // cell-LN nets at UT = 1, N <= 512: the forward kernel with one exchange fewer per step
+    const bool fused_cln = !backward && A.cell_ln && UT == 1 && A.KSP / 16 <= 8;
+    if (!backward) lds = ((size_t)UT * A.KSP * 64 + UT * 4 * 256) * 4 + 64 + (fused_cln ? 1024 : 0);
     else lds = ((size_t)UT * A.KT * 256 + UT * 256 + UT * 1024) * 4 + 64;
     if (lds > 160 * 1024) return ASR_ERR_ARG;
 
@@ -782,7 +1028,10 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
         do { hipFuncSetAttribute((const void*)K<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
              hipLaunchKernelGGL((K<U>), grid, block, lds, stream, Al); } while (0)
         if (!backward) {
-            if (UT == 1) LAUNCH_(lstm_scan_fwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_fwd_kernel, 2);
+            if (fused_cln) {
+                hipFuncSetAttribute((const void*)lstm_scan_fwd_cln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(lstm_scan_fwd_cln_kernel, grid, block, lds, stream, Al);
+            } else if (UT == 1) LAUNCH_(lstm_scan_fwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_fwd_kernel, 2);
             else LAUNCH_(lstm_scan_fwd_kernel, 4);
         } else {
             if (UT == 1) LAUNCH_(lstm_scan_bwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_bwd_kernel, 2);
