@@ -930,6 +930,9 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
         A.dhx = (float*)p;  p += ng * 2 * (size_t)A.G * A.G * A.UH * 16 * 4;
         A.dgx = (float*)p;
     }
+    // one workgroup per CU whenever the grid fits the chip that way (the sc1 hand-off is measured for one workgroup per
+    // CU: MI355X_MICROARCH.md, table under 'Valid forms'): ask for more than half of a CU's 160 KB
+    if ((size_t)A.G * d->ndir * nchunk <= 256 && lds < 82 * 1024) lds = 82 * 1024;
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
     A.dbg = (unsigned long long*)((char*)ws + asr_hyper_scan_ws_bytes(d->T, d->B, d->N, d->H, d->ndir, backward) - STAMP_BYTES);
     int cpl = cap / (A.G * d->ndir);

@@ -1017,6 +1017,9 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     if (!backward) lds = ((size_t)UT * A.KSP * 64 + UT * 4 * 256) * 4 + 64 + (fused_cln ? 1024 : 0);
     else lds = ((size_t)UT * A.KT * 256 + UT * 256 + UT * 1024) * 4 + 64;
     if (lds > 160 * 1024) return ASR_ERR_ARG;
+    // one workgroup per CU (what the sc1 hand-off is measured for, MI355X_MICROARCH.md 'Valid forms'): a launch
+    // never exceeds 256 workgroups, so asking for more than half of a CU's 160 KB spreads them one per CU
+    if (lds < 82 * 1024) lds = 82 * 1024;
 
     for (int c0 = 0; c0 < nchunk_total; c0 += cpl) {
         const int nc = (nchunk_total - c0 < cpl) ? nchunk_total - c0 : cpl;
