@@ -413,6 +413,11 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
                 if (q == 0)
                     st_sc1_f4(rex_rs, (unsigned)((((size_t)(par ^ 1) * KSP + tile) * 64 + bl * 4) * 4), f32x4{r, r1, r2, r3});
             }
+        }
+        STAMP(5);
+        group_publish(gs);
+        STAMP(6);
+        if (wave < UT) {                                 // bulk saves behind the publish: off the critical path
             if (bvalid) {
                 *q_r = r;
                 *q_c = c;
@@ -431,9 +436,6 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
             }
             q_r += z_r; q_c += z_c; q_g += z_g; q_ah += z_ah; q_ra += z_ra; q_ch += z_ch; q_rc += z_rc;
         }
-        STAMP(5);
-        group_publish(gs);
-        STAMP(6);
     }
     STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) 
             for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)w * 64 + lane) * 4);
         }
         float rs_a = 0.f;
-        f32x4 rs_a4 = {0, 0, 0, 0}, ah4 = {0, 0, 0, 0};
+        f32x4 rs_a4 = {0, 0, 0, 0}, ah4 = {0, 0, 0, 0}, sv_g4 = {0, 0, 0, 0};
         if (A.ln_kind && !A.per_gate) {
             if (own) {
                 const float mj = sum_q(a4[0] + a4[1] + a4[2] + a4[3]) * (1.0f / 16.0f);
@@ -664,9 +666,14 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) 
                     st_sc1_f4(rex_rs, base + 256u, f32x4{og, o1, o2, o3});
                 }
             }
+            sv_g4 = f32x4{ig, fg, gg, og};
+        }
+        m_prev = m;
+        group_publish(gs);
+        if (own) {                                       // bulk saves behind the publish: off the critical path
             if (bvalid) {
                 *q_c = c;
-                if (q_g) *(f32x4*)q_g = f32x4{ig, fg, gg, og};
+                if (q_g) *(f32x4*)q_g = sv_g4;
                 if (q_ah) {
                     *(f32x4*)q_ah = ah4;
                     if (lead) {
@@ -677,8 +684,6 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) 
             }
             q_c += z_c; q_g += z_g; q_ah += z_ah; q_ra += z_ra;
         }
-        m_prev = m;
-        group_publish(gs);
     }
 }
 
@@ -837,9 +842,10 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             if (wave < UT) {
                 const float s1 = sum_q(dxh), s2 = sum_q(dxh * chat_v);
                 if (q == 0) st_sc1_f2(stc + ((size_t)par * KS + tile) * 32 + bl * 2, s1, s2);
-                if (bvalid && q_do) *q_do = dout;
             }
             group_publish(gs);
+            // bulk saves go behind the publish (its vmcnt(0) drain would wait for them), under the exchange
+            if (wave < UT && bvalid && q_do) *q_do = dout;
             if (!group_wait(gs)) break;
             STAMP(2);
             {
@@ -861,7 +867,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             dr_pass = dr_t;
         }
         f32x4 da4 = dg4;
-        if (wave < UT && bvalid) *(f32x4*)q_dg = dg4;
+        bool dg_pending = wave < UT && bvalid;
         STAMP(3);
         if (A.ln_kind) {
             f32x4 dah = {0, 0, 0, 0};
@@ -881,6 +887,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
                 }
             }
             group_publish(gs);
+            if (dg_pending) { *(f32x4*)q_dg = dg4; dg_pending = false; }
             if (!group_wait(gs)) break;
             STAMP(4);
             {
@@ -895,7 +902,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
                     da4 = rs_a4 * (dah - s14 * (1.0f / N) - ah4 * (s24 * (1.0f / N)));
                 }
             }
-            if (wave < UT && bvalid && q_da) *(f32x4*)q_da = da4;
+
         }
         // 3. partial dr_{prev}: B operand needs da[b][col 4e+(l>>4)] -> go through LDS
         if (wave < UT) {
@@ -922,6 +929,8 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
             group_publish(gs);
             STAMP(7);
         }
+        if (dg_pending) *(f32x4*)q_dg = dg4;
+        if (wave < UT && bvalid && q_da) *(f32x4*)q_da = da4;
         c0v = c1v; c1v = n_c2;
         q_dg += z_dg; q_da += z_da; q_do += z_do;
     }
