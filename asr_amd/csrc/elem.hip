@@ -260,6 +260,35 @@ extern "C" int asr_act_bwd(float* dy, const float* y, int rows, int n, int act, 
     return ASR_OK;
 }
 
+// rows are (t,b) time-major: y[r, :] = a[b, :] * x[r, :] + c0[b, :] + mask[b, t] * c1[b, :]  (b = r % B, t = r / B).
+// Gradient of the sequence-variance costs on the inner hidden sequences of scripts/hypernets/exp_prj_hyper.py:108-124
+// with respect to those sequences: the three (B, n) coefficient matrices are formed on the host from the per-row
+// sums (asr_seq_pool_fwd mode 2, asr_colreduce with gmod = B).
+__global__ void affine_rows_kernel(const float* x, int ldx, const float* a, const float* c0, const float* c1,
+                                   const float* mask, int msb, int mst, int B, float* y, int ldy, size_t rows, int n) {
+    size_t tot = rows * n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / n;
+        const int c = (int)(i % n);
+        const size_t b = r % B, t = r / B;
+        const size_t k = b * n + c;
+        y[r * ldy + c] = a[k] * x[r * ldx + c] + c0[k] + mask[b * msb + t * mst] * c1[k];
+    }
+}
+extern "C" int asr_affine_rows(const float* x, int ldx, const float* a, const float* c0, const float* c1,
+                               const float* mask, int mask_stride_b, int mask_stride_t, int B, float* y, int ldy,
+                               int rows, int n, hipStream_t stream) {
+    if (rows < 0 || n <= 0 || B <= 0 || !x || !a || !c0 || !c1 || !mask || !y || rows % B) return ASR_ERR_ARG;
+    size_t tot = (size_t)rows * n;
+    if (!tot) return ASR_OK;
+    int grid = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+    hipLaunchKernelGGL(affine_rows_kernel, dim3(grid), dim3(256), 0, stream, x, ldx, a, c0, c1, mask, mask_stride_b,
+                       mask_stride_t, B, y, ldy, (size_t)rows, n);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
 // rows are (t,b) time-major: y[r, :] = x[r, :] * s[r % B, :] (s optionally passed through relu)
 // LHUC epilogue (libs/lhuclstm_layers.py:461-462) and its gradient wrt the hidden sequence.
 __global__ void rowscale_kernel(const float* x, int ldx, const float* s, int B, int relu, float* y,

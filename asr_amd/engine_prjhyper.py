@@ -5,6 +5,7 @@ where nothing below depends on them).  The layer's output fed upward is the OUTE
 direction (models/gating_hyper_nets.py:150-171); the inner one is kept for `get_inner_hid`.
 Gate vectors stay in the reference's gate-major layout here (no interleave)."""
 import ctypes as C
+import numpy as np
 import torch
 
 from . import _lib, ops, specs
@@ -53,6 +54,7 @@ class PrjHyperPair(object):
         self.out_dim = ndir * F
         self.dirs = [_mk_prj(net.store, 'L%d.%d.' % (idx, d), D, N, F) for d in range(ndir)]
         self.reverse = [False, True][:ndir]
+        self.inner_grad = [None] * ndir   # gradient on the inner hidden sequences, consumed by the next backward
 
     def describe(self):
         out = {}
@@ -71,6 +73,41 @@ class PrjHyperPair(object):
 
     def inner_hid(self, d):
         return self.ctx['d'][d]['hid'][:, :self.F]
+
+    def aux_costs(self, w_inter=0.0, w_intra=0.0):
+        """scripts/hypernets/exp_prj_hyper.py:108-124 on the inner hidden sequences of the last forward:
+        returns (train_inter_cost, train_intra_cost); with a non-zero weight the gradient of
+        w_inter*inter + w_intra*intra with respect to those sequences is left for the next backward.
+        Per-row sums on the device (masked mean: asr_seq_pool_fwd mode 2; unmasked sum and sum of squares over
+        time: asr_colreduce with gmod = B), the (B,F) algebra on the host, the gradient by asr_affine_rows."""
+        ctx = self.ctx; T, B, mask = ctx['T'], ctx['B'], ctx['mask']
+        F = self.F; rows = T * B
+        st = self._buf('aux_st', 3 * self.ndir * B, F)
+        for d in range(self.ndir):
+            feat = self.inner_hid(d)                                  # (rows, F) view, leading dimension 2F
+            o = 3 * d * B
+            ops.seq_pool_fwd(feat, 2 * F, B * 2 * F, mask.contiguous(), B, T, F, 2, st[o:o + B])
+            ops.colreduce(feat, st[o + B:o + 2 * B], rows, F, gmod=B, ldx=2 * F)
+            ops.colreduce(feat, st[o + 2 * B:o + 3 * B], rows, F, y=feat, gmod=B, ldx=2 * F, ldy=2 * F)
+        h = st.detach().cpu().numpy().astype(np.float64).reshape(self.ndir, 3, B, F)
+        L = mask.sum(1).cpu().numpy().astype(np.float64)[:, None]
+        inter = 0.0; intra = 0.0
+        want = (w_inter != 0.0) or (w_intra != 0.0)
+        if want and getattr(self.net, 'world', 1) > 1:
+            raise NotImplementedError('asr_amd: the inter / intra costs are batch statistics of one process')
+        for d in range(self.ndir):
+            mu, S0, S2 = h[d]
+            seq_var = (S2 - 2.0 * mu * S0 + T * mu * mu) / L
+            inter += -0.5 * float(np.mean(mu.var(0))); intra += 0.5 * float(np.mean(seq_var))
+            if want:
+                a = (w_intra / (B * F)) / L * np.ones_like(mu)
+                c0 = -a * mu
+                c1 = -w_intra * (S0 - T * mu) / (B * F * L * L) - w_inter * (mu - mu.mean(0)) / (F * B * L)
+                co = torch.from_numpy(np.stack([a, c0, c1]).astype(np.float32)).to(st.device)
+                g = self._buf('aux_g%d' % d, rows, F)
+                ops.affine_rows(self.inner_hid(d), 2 * F, co[0], co[1], co[2], mask, B, g, F, rows, F)
+                self.inner_grad[d] = g
+        return inter, intra
 
     _SAVE = (('gi', 4), ('go', 4), ('ci', 1), ('co', 1), ('ri', 1), ('ro', 1), ('xhi', 1), ('xho', 1), ('sc', 12), ('a', 4))
     _BWD = (('dii', 4), ('doi', 4), ('dsc', 12), ('da', 4), ('douti', 1), ('douto', 1))
@@ -131,7 +168,10 @@ class PrjHyperPair(object):
         for d in range(self.ndir):
             c = ctx['d'][d]
             c['dhid'] = self._buf('dhid%d' % d, rows, 2 * F)
-            c['dhid'].zero_()
+            if self.inner_grad[d] is None:
+                c['dhid'][:, :F].zero_()
+            else:
+                c['dhid'][:, :F].copy_(self.inner_grad[d]); self.inner_grad[d] = None
             c['dhid'][:, F:].copy_(dY[:, d * F:(d + 1) * F])
             c['dh'] = self._buf('dh%d' % d, rows, 2 * F)
             for nm, w in self._BWD:

@@ -93,6 +93,12 @@ def rowscale(x, ldx, s, B, relu, y, ldy, rows, n):
     return y
 
 
+def affine_rows(x, ldx, a, c0, c1, mask, B, y, ldy, rows, n):
+    check(_lib.lib().asr_affine_rows(_p(x), ldx, _p(a), _p(c0), _p(c1), _p(mask), mask.stride(0), mask.stride(1), B,
+                                     _p(y), ldy, rows, n, _s()), 'asr_affine_rows')
+    return y
+
+
 def masked_mean(x, mask, B, T, F, out):
     check(_lib.lib().asr_masked_mean(_p(x), _p(mask), B, T, F, _p(out), _s()), 'asr_masked_mean')
     return out

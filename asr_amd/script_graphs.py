@@ -81,6 +81,40 @@ def build_trainer(input_data, input_mask, target_data, target_mask, network_para
     return training_fn, train_lr, updater_params
 
 
+def build_prj_hyper_trainer(input_data, input_mask, target_data, target_mask, network_params, output_layer,
+                            fwd_inner_layer, bwd_inner_layer, updater, inter_weight, intra_weight, learning_rate,
+                            load_updater_params=None):
+    """scripts/hypernets/exp_prj_hyper.py:70-146: CE/B + inter_weight*inter + intra_weight*intra, where the two
+    costs are the batch / time variances of the inner hidden sequences of the ProjectionHyper layer
+    (asr_amd.engine_prjhyper.PrjHyperPair.aux_costs).  Returns (training_fn, updater_params) as the reference
+    does; training_fn -> [frame_loss, frame_accr, grads_norm, inter_cost, intra_cost]."""
+    network = output_layer
+    pair = fwd_inner_layer.pair
+    if bwd_inner_layer.pair is not pair:
+        raise ValueError('asr_amd: the two inner layers must come from one deep_projection_hyper_model call')
+    train_lr = SharedScalar(learning_rate, 'train_lr')
+    update, updater_params = updater(loss_or_grads=None, params=network_params, learning_rate=train_lr,
+                                     load_params_dict=load_updater_params)
+    red = _reducer(network)
+    f32 = torch.float32
+
+    def training_fn(x, mask, y, ymask):
+        ym = _dev(network, ymask, f32)
+        ce, ok, _ = network.loss(_dev(network, x, f32), _dev(network, mask, f32), _dev(network, y, torch.int32),
+                                 ym, cond=None, train=True)
+        inter, intra = pair.aux_costs(float(inter_weight), float(intra_weight))
+        network.backward()
+        red.finish()
+        gn = update.apply(network, want_sqrt=True)
+        out = torch.cat([ce, ok, gn, ym.sum().reshape(1)]).cpu().numpy()
+        network.check_status()
+        nfr = max(float(out[3]), 1.0)
+        return [np.float32(out[0] / nfr), np.float32(out[1] / nfr), np.float32(out[2]), np.float32(inter),
+                np.float32(intra)]
+
+    return training_fn, updater_params
+
+
 def build_predictor(input_data, input_mask, target_data, target_mask, output_layer):
     network = output_layer
     f32 = torch.float32

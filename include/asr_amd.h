@@ -67,6 +67,11 @@ int asr_bias_act(float* x, const float* bias, int rows, int n, int act, asr_stre
 int asr_act_bwd(float* dy, const float* y, int rows, int n, int act, asr_stream_t stream);
 int asr_rowscale(const float* x, int ldx, const float* s, int B, int relu, float* y, int ldy, int rows,
                  int n, asr_stream_t stream);                 /* LHUC, libs/lhuclstm_layers.py:461-462 */
+/* y[r,:] = a[b,:]*x[r,:] + c0[b,:] + mask[b,t]*c1[b,:] over time-major rows r = t*B + b: the gradient of the
+ * inter / intra variance costs on the inner hidden sequences, scripts/hypernets/exp_prj_hyper.py:108-124 */
+int asr_affine_rows(const float* x, int ldx, const float* a, const float* c0, const float* c1, const float* mask,
+                    int mask_stride_b, int mask_stride_t, int B, float* y, int ldy, int rows, int n,
+                    asr_stream_t stream);
 int asr_masked_mean(const float* x, const float* mask, int B, int T, int F, float* out,
                     asr_stream_t stream);
 int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, const float* pre, int B, int T, int F,

@@ -1015,12 +1015,13 @@ class HyperLHUCLSTMLayerO(OracleLayer):
 
 class ProjectionHyperLSTMLayerO(OracleLayer):
     """libs/lasagne_libs/hyper_layers.py:14-523.  forward returns [inner_hid | outer_hid] (:519); the
-    builder feeds the outer half upward (models/gating_hyper_nets.py:150-171).  Oracle only so far: the
-    HIP path for this class is not built yet."""
+    builder feeds the outer half upward (models/gating_hyper_nets.py:150-171).  `d_inner` (B,T,F), when set
+    before backward, is the gradient that a cost on the inner hidden sequence sends in (prj_hyper_aux_costs)."""
     def __init__(self, P, num_factors, num_units, grad_clipping=0, backwards=False, only_outer=False):
         self.P = P
         self.spec = dict(N=num_units, F=num_factors, grad_clip=grad_clipping, backwards=backwards)
         self.only_outer = only_outer      # the builder's SliceLayer(indices=slice(num_factors, None)) (:150-152)
+        self.d_inner = None
 
     def forward(self, x, mask, cond=None):
         P = self.P; G = GATES_REC
@@ -1042,7 +1043,8 @@ class ProjectionHyperLSTMLayerO(OracleLayer):
         F = self.spec['F']; N = self.spec['N']
         dyt = _tm(dy)
         if self.only_outer:
-            dyt = np.concatenate([np.zeros_like(dyt), dyt], axis=-1)
+            di = np.zeros(dyt.shape[:2] + (F,), dyt.dtype) if self.d_inner is None else _tm(np.asarray(self.d_inner, dyt.dtype))
+            dyt = np.concatenate([di, dyt], axis=-1)
         dx, g = prjhyper_scan_bwd(dyt[:, :, :F], dyt[:, :, F:], self.x, self.cache, self.p, self.spec)
         G = {}; G4 = GATES_REC
         for key, fmt in (('Wi_x', 'W_in_to_inner_{}'), ('Wi_i', 'W_inner_to_inner_{}'), ('Wi_o', 'W_outer_to_inner_{}'),
@@ -1199,6 +1201,29 @@ _KINDS = dict(lstm=LSTMLayerO, lhuc=LHUCLSTMLayerO, prj=ProjectLSTMLayerO,
               hyperlhuc=HyperLHUCLSTMLayerO, prjhyper=ProjectionHyperLSTMLayerO)
 
 
+def prj_hyper_aux_costs(feats, mask, w_inter=0.0, w_intra=0.0):
+    """scripts/hypernets/exp_prj_hyper.py:108-124: for each inner hidden sequence (B,T,F): the masked mean over
+    time (:108-109), the variance over time around it with an UNMASKED sum of squares divided by the masked
+    length (:112-113), the population variance of the means over the batch (:116-117);
+    inter = -0.5 * sum_dirs mean(sample_var), intra = 0.5 * sum_dirs mean(seq_var) (:120-121).
+    Returns (inter, intra, [d(w_inter*inter + w_intra*intra)/d feat for each feat])."""
+    mask = np.asarray(mask, np.float64)
+    m = mask[:, :, None]; L = mask.sum(1)[:, None]                     # (B,1)
+    inter = 0.0; intra = 0.0; grads = []
+    for x in feats:
+        x = np.asarray(x, np.float64)
+        B, T, F = x.shape
+        mu = (x * m).sum(1) / L                                        # (B,F)
+        dev = x - mu[:, None, :]
+        seq_var = (dev ** 2).sum(1) / L
+        sample_var = mu.var(0)
+        inter += -0.5 * sample_var.mean(); intra += 0.5 * seq_var.mean()
+        d_intra = (0.5 / (B * F)) * (2.0 * dev / L[:, :, None] - m * (2.0 / L[:, :, None] ** 2) * dev.sum(1)[:, None, :])
+        d_inter = (-0.5 / F) * (2.0 * (mu - mu.mean(0)) / B)[:, None, :] * m / L[:, :, None]
+        grads.append(w_intra * d_intra + w_inter * d_inter)
+    return inter, intra, grads
+
+
 class OracleNetwork(object):
     def __init__(self, desc, values, dtype=np.float64):
         self.desc = desc
@@ -1261,8 +1286,19 @@ class OracleNetwork(object):
         lg = self.forward(x, mask, cond)
         return np.exp(log_softmax(lg)) if self.desc['output'] == 'softmax' else lg
 
-    def loss_and_grads(self, x, mask, target, target_mask, cond=None, context=0):
+    def loss_and_grads(self, x, mask, target, target_mask, cond=None, context=0, aux=None):
+        """aux = (w_inter, w_intra): adds the exp_prj_hyper.py costs on the inner hidden sequences of the first
+        (ProjectionHyper) layer pair to the loss; self.aux_costs then holds (inter, intra)."""
         lg = self.forward(x, mask, cond)
+        for pair in self.layers:
+            for l in pair:
+                if l is not None and hasattr(l, 'd_inner'):
+                    l.d_inner = None
+        if aux is not None:
+            f0, b0 = self.layers[0]
+            inter, intra, dg = prj_hyper_aux_costs([f0.inner_hid, b0.inner_hid], mask, aux[0], aux[1])
+            self.aux_costs = (inter, intra)
+            f0.d_inner, b0.d_inner = dg
         tm = np.asarray(target_mask, self.dtype)
         if context:                                        # libs/comp_graph_utils.py:26-27,54-55
             tm = tm.copy(); tm[:, context:] = 0

@@ -296,6 +296,37 @@ def test_projection_hyper_small(clip):
         assert relerr(got, onet.layers[0][d].inner_hid) < 2e-5
 
 
+def test_projection_hyper_aux_costs_and_trainer():
+    """scripts/hypernets/exp_prj_hyper.py:70-146: the inter / intra variance costs on the inner hidden sequences
+    and their gradient through the whole net, against the oracle (weights 0.7 / 1.3); then the trainer's outputs."""
+    from asr_amd.gating_hyper_nets import deep_projection_hyper_model
+    from asr_amd import script_graphs, updates
+    net, fi, bi = deep_projection_hyper_model(None, None, 5, 6, 2, 4, 8, grad_clipping=1.0, device=_dev(), seed=71)
+    perturb_params(net, 72, 0.15)
+    b = make_batch(np.random.default_rng(73), 4, 7, 5, 6)
+    dev = net.device
+    x, m, y = (torch.from_numpy(b[k]).to(dev) for k in ('x', 'mask', 'y'))
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    oc, os_, opred, ograds = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], aux=(0.7, 1.3))
+    net.loss(x, m, y, m, None, train=True)
+    inter, intra = fi.pair.aux_costs(0.7, 1.3)
+    net.backward()
+    net.check_status()
+    assert abs(inter - onet.aux_costs[0]) < 1e-5 * max(1.0, abs(onet.aux_costs[0]))
+    assert abs(intra - onet.aux_costs[1]) < 1e-5 * max(1.0, abs(onet.aux_costs[1]))
+    for (n, _), g, og in zip(net.param_names_shapes(), net.get_all_grad_values(), ograds):
+        assert relerr(g, og) < 1e-4, n
+    # without weights nothing is injected: gradients equal the plain CE ones
+    _, _, _, og0 = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    assert max(relerr(a_, b_) for a_, b_ in zip(ograds, og0)) > 1e-3          # the costs do matter in this case
+    tf, up = script_graphs.build_prj_hyper_trainer(None, None, None, None, net.get_all_params(trainable=True), net,
+                                                   fi, bi, updates.momentum, 0.7, 1.3, 1e-3)
+    out = tf(b['x'], b['mask'], b['y'], b['mask'])
+    assert len(out) == 5 and all(np.isfinite(v) for v in out)
+    assert abs(out[3] - onet.aux_costs[0]) < 1e-4 and abs(out[4] - onet.aux_costs[1]) < 1e-4
+    assert abs(out[0] - os_ / b['mask'].sum()) < 1e-4 * max(1.0, os_ / b['mask'].sum())
+
+
 def test_projection_hyper_medium():
     """B = 18 (two batch chunks), N = 64, F = 32."""
     from asr_amd.gating_hyper_nets import deep_projection_hyper_model

@@ -222,3 +222,22 @@ def test_seqsum_lhuc_network():
     for g, t in zip(grads, tv):
         np.testing.assert_allclose(g, t.grad.numpy(), rtol=1e-7, atol=1e-10)
     assert np.abs(grads[0]).max() > 1e-6          # the embedding path really carries gradient
+
+
+def test_prj_hyper_aux_costs_gradient_by_finite_differences():
+    """oracle/asr_oracle.py:prj_hyper_aux_costs (scripts/hypernets/exp_prj_hyper.py:108-124)."""
+    from oracle import asr_oracle as O
+    rng = np.random.default_rng(0)
+    B, T, F = 3, 6, 4
+    mask = (np.arange(T)[None, :] < np.array([6, 1, 4])[:, None]).astype(float)
+    fe = [rng.standard_normal((B, T, F)) for _ in range(2)]
+    wi, wa = 0.7, 1.3
+    _, _, g = O.prj_hyper_aux_costs(fe, mask, wi, wa)
+    eps = 1e-6
+    for d in range(2):
+        for _ in range(12):
+            idx = tuple(int(rng.integers(0, s)) for s in (B, T, F))
+            fp = [f.copy() for f in fe]; fp[d][idx] += eps
+            fm = [f.copy() for f in fe]; fm[d][idx] -= eps
+            ip, ap, _ = O.prj_hyper_aux_costs(fp, mask); im, am, _ = O.prj_hyper_aux_costs(fm, mask)
+            assert abs((wi * (ip - im) + wa * (ap - am)) / (2 * eps) - g[d][idx]) < 1e-7
