@@ -96,14 +96,63 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float* __restric
     }
 }
 
+// the same with the row held in registers (n <= 256 NV): one read of x, every load issued before the first use
+template <int NV>
+__global__ __launch_bounds__(256) void ln_rows_fwd_reg_kernel(const float* __restrict__ x, int n,
+                                                              const float* __restrict__ pre, int pmod,
+                                                              const float* __restrict__ alpha,
+                                                              const float* __restrict__ beta, int amod,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ y, float* __restrict__ xhat,
+                                                              float* __restrict__ rstd, int groups) {
+    __shared__ float sm[16];
+    const size_t r = blockIdx.x;
+    const float* xr = x + r * n;
+    const float* pr = pre ? pre + (size_t)(r % pmod) * n : nullptr;
+    const size_t ra = amod ? r % amod : 0;
+    const float ng = (float)(n / groups);
+    float v[NV], al[NV], be[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        const int cc = c < n ? c : n - 1;
+        v[k] = xr[cc] + (pr ? pr[cc] : 0.f);
+        al[k] = alpha[ra * n + cc];
+        be[k] = (beta ? beta[ra * n + cc] : 0.f) + (bias ? bias[cc] : 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (threadIdx.x + 256 * k < n) ? v[k] : 0.f;
+    const float mean = block_sum_any(s, sm, groups) / ng;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { const float d = v[k] - mean; q += (threadIdx.x + 256 * k < n) ? d * d : 0.f; }
+    const float var = block_sum_any(q, sm, groups) / ng;
+    const float rs = 1.0f / sqrtf(var + ASR_EPS);
+    if (rstd && threadIdx.x < groups) rstd[r * groups + threadIdx.x] = rs;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < n) {
+            const float xh = (v[k] - mean) * rs;
+            if (xhat) xhat[r * n + c] = xh;
+            y[r * n + c] = al[k] * xh + be[k];
+        }
+    }
+}
+
 extern "C" int asr_ln_rows_fwd(const float* x, int rows, int n, const float* pre, int pmod,
                                const float* alpha, const float* beta, int amod, const float* bias,
                                float* y, float* xhat, float* rstd, int groups, hipStream_t stream) {
     if (rows < 0 || n <= 0 || !x || !y || !alpha || (groups != 1 && groups != 4) || n % groups) return ASR_ERR_ARG;
     if (pre && pmod <= 0) return ASR_ERR_ARG;
     if (rows == 0) return ASR_OK;
-    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(rows), dim3(256), 0, stream, x, n, pre, pmod, alpha,
-                       beta, amod, bias, y, xhat, rstd, groups);
+#define LN_FWD_(NV_) hipLaunchKernelGGL((ln_rows_fwd_reg_kernel<NV_>), dim3(rows), dim3(256), 0, stream, x, n, pre, \
+                                        pmod, alpha, beta, amod, bias, y, xhat, rstd, groups)
+    if (n <= 1024) LN_FWD_(4); else if (n <= 2048) LN_FWD_(8); else if (n <= 4096) LN_FWD_(16);
+    else hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(rows), dim3(256), 0, stream, x, n, pre, pmod, alpha,
+                            beta, amod, bias, y, xhat, rstd, groups);
+#undef LN_FWD_
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
@@ -133,13 +182,52 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
     }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void ln_rows_bwd_reg_kernel(const float* __restrict__ dy, int n,
+                                                              const float* __restrict__ xhat,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ alpha, int amod,
+                                                              float* __restrict__ dx, int groups) {
+    __shared__ float sm[16];
+    const size_t r = blockIdx.x;
+    const size_t ra = amod ? r % amod : 0;
+    const float ng = (float)(n / groups);
+    float d[NV], xh[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        const int cc = c < n ? c : n - 1;
+        d[k] = dy[r * n + cc] * alpha[ra * n + cc];
+        xh[k] = xhat[r * n + cc];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const bool ok = threadIdx.x + 256 * k < n;
+        s1 += ok ? d[k] : 0.f;
+        s2 += ok ? d[k] * xh[k] : 0.f;
+    }
+    const float m1 = block_sum_any(s1, sm, groups) / ng;
+    const float m2 = block_sum_any(s2, sm, groups) / ng;
+    const float rs = rstd[r * groups + (groups == 4 ? (threadIdx.x & 3) : 0)];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < n) dx[r * n + c] = rs * (d[k] - m1 - xh[k] * m2);
+    }
+}
+
 extern "C" int asr_ln_rows_bwd(const float* dy, int rows, int n, const float* xhat, const float* rstd,
                                const float* alpha, int amod, float* dx, int groups, hipStream_t stream) {
     if (rows < 0 || n <= 0 || !dy || !xhat || !rstd || !alpha || !dx || (groups != 1 && groups != 4) || n % groups)
         return ASR_ERR_ARG;
     if (rows == 0) return ASR_OK;
-    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(rows), dim3(256), 0, stream, dy, n, xhat, rstd, alpha,
-                       amod, dx, groups);
+#define LN_BWD_(NV_) hipLaunchKernelGGL((ln_rows_bwd_reg_kernel<NV_>), dim3(rows), dim3(256), 0, stream, dy, n, xhat, \
+                                        rstd, alpha, amod, dx, groups)
+    if (n <= 1024) LN_BWD_(4); else if (n <= 2048) LN_BWD_(8); else if (n <= 4096) LN_BWD_(16);
+    else hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(rows), dim3(256), 0, stream, dy, n, xhat, rstd, alpha,
+                            amod, dx, groups);
+#undef LN_BWD_
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
