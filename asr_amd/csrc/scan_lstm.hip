@@ -198,6 +198,7 @@ __device__ __forceinline__ void combine_sums4(const float* st, int KS, int tid, 
 // ------------------------------------------------------------------------------------------------
 template <int UT>
 __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
+    __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // [UT][KSP/4][64][4]
     float* red = Wl + (size_t)UT * A.KSP * 64;          // [UT][4 waves][64][4]
@@ -455,6 +456,7 @@ __device__ __forceinline__ float tanh_rcp_(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 __global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) {
+    __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // [KSP/4][64][4]
     float* red = Wl + (size_t)A.KSP * 64;               // [4 waves][64][4]
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) 
 // ------------------------------------------------------------------------------------------------
 template <int UT>
 __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
+    __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wb = smem;                                   // [UT][KT][64][4]
     float* dal = Wb + (size_t)UT * A.KT * 256;          // [UT][16 cols][16 b]
