@@ -82,6 +82,7 @@ _SIGS = {
     'asr_norm_clip_mult': (i32, [fp, f32, f32, fp, fp]),
     'asr_lstm_pack_floats': (sz, [i32, i32]),
     'asr_lstm_pack_w': (i32, [fp, i32, i32, fp, fp]),
+    'asr_lstm_bwd_pack_mode': (i32, [i32, i32, i32]),
     'asr_lstm_scan_ws_bytes': (sz, [i32, i32, i32, i32, i32]),
     'asr_lstm_scan_fwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),
     'asr_lstm_scan_bwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),

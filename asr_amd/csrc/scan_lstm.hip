@@ -65,10 +65,13 @@ struct LstmScanArgs {
 //  mode 0 (forward A-fragments):  out[tile][s4][l][e] = W[4*(4*s4+(l>>4)) + e][tile*16 + (l&15)]
 //          (MFMA k index l>>4 <-> source tile 4*s4+k, the 4 steps e of a group <-> the tile's 4 units)
 //  mode 1 (backward A-fragments): out[tile][kt][l][e] = W[kt*16 + (l&15)][tile*16 + 4*e + (l>>4)]
+//  mode 2 (backward, 2-D decomposition of lstm_scan_bwd_ln2d_kernel; N % 128 == 0):
+//          out[j = ub*8+kr][wave][i][t][l][e] = W[ub*32 + t*16 + (l&15)][16*(kr*KS/8 + wave*TW + i) + 4*(l>>4) + e]
 // rows/steps beyond N are zero.
 __global__ void lstm_pack_kernel(const float* __restrict__ W, int N, int KS, int KSP, int KT, int mode,
                                  float* __restrict__ out) {
-    const int per_tile = mode == 0 ? KSP * 64 : KT * 256;
+    const int TW = KS / 32;                             // mode 2: source tiles per wave
+    const int per_tile = mode == 0 ? KSP * 64 : mode == 1 ? KT * 256 : TW * 2048;
     const size_t tot = (size_t)KS * per_tile;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -77,7 +80,12 @@ __global__ void lstm_pack_kernel(const float* __restrict__ W, int N, int KS, int
         const int e = r & 3, l = (r >> 2) & 63, blk = r >> 8;
         int row, col;
         if (mode == 0) { row = 4 * (4 * blk + (l >> 4)) + e; col = tile * 16 + (l & 15); }
-        else           { row = blk * 16 + (l & 15);          col = tile * 16 + 4 * e + (l >> 4); }
+        else if (mode == 1) { row = blk * 16 + (l & 15);     col = tile * 16 + 4 * e + (l >> 4); }
+        else {              // workgroup `tile` = (ub, kr); blk = (wave * TW + i) * 2 + t
+            const int ub = tile / 8, kr = tile % 8, t = blk & 1, wi = blk >> 1;
+            row = ub * 32 + t * 16 + (l & 15);
+            col = 16 * (kr * (KS / 8) + wi) + 4 * (l >> 4) + e;
+        }
         out[i] = row < N ? W[(size_t)row * 4 * N + col] : 0.0f;
     }
 }
@@ -91,11 +99,20 @@ static inline void lstm_dims(int N, int* KS, int* KSP, int* KT) {
 extern "C" size_t asr_lstm_pack_floats(int N, int mode) {
     int KS, KSP, KT;
     lstm_dims(N, &KS, &KSP, &KT);
-    return mode == 0 ? (size_t)KS * KSP * 64 : (size_t)KS * KT * 256;
+    return mode == 0 ? (size_t)KS * KSP * 64 : mode == 1 ? (size_t)KS * KT * 256 : (size_t)KS * (KS / 32) * 2048;
+}
+
+// Which packing the backward scan of a layer expects (1 or 2): 2 = the 2-D decomposition, taken for row-LN
+// variants (ln_kind 1 / 2) whose grid is one workgroup per 4 units (N/4 * ndir <= 256) with N a multiple of 128,
+// N <= 512.  The caller packs W with this mode and the launcher selects the kernel by the same rule.
+extern "C" int asr_lstm_bwd_pack_mode(int N, int ndir, int ln_kind) {
+    if ((ln_kind == 1 || ln_kind == 2) && N > 0 && N % 128 == 0 && N <= 512 && ndir >= 1 && (N / 4) * ndir <= 256)
+        return 2;
+    return 1;
 }
 
 extern "C" int asr_lstm_pack_w(const float* W, int N, int mode, float* out, hipStream_t stream) {
-    if (!W || !out || N <= 0 || (N & 3)) return ASR_ERR_ARG;
+    if (!W || !out || N <= 0 || (N & 3) || mode < 0 || mode > 2 || (mode == 2 && N % 128)) return ASR_ERR_ARG;
     int KS, KSP, KT;
     lstm_dims(N, &KS, &KSP, &KT);
     size_t tot = asr_lstm_pack_floats(N, mode);
@@ -941,6 +958,227 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, row-LN variants (ln_kind 1 / 2, not per gate) at UT = 1 with G = N/4 a multiple of 32 and N <= 512:
+// the dr_{t-1} = da . W'^T product as a 2-D decomposition instead of the all-to-all of per-destination
+// partials (32 KB written and 32 KB read per workgroup and step).  Workgroup j = (unit block ub = j / 8,
+// member kr = j % 8):
+//   * with the gate-LN statistics exchange every workgroup also publishes dah = dg * alpha of its own 16
+//     columns (1 KB); the statistics turn any column's dah into da = rstd * (dah - m1 - ahat * m2), ahat
+//     being the saved forward tensor (read straight from HBM, one step ahead);
+//   * member kr forms da for ITS eighth of the 4N columns (16 KB of dah gathered, 16 KB of ahat) and
+//     multiplies it with the rows of W' of the block's 32 units: a (32 units x 16 batch) partial = 2 KB,
+//     published with the step's last exchange;
+//   * at the top of the next step a workgroup sums the 8 members' partials of its own 4 units (8 x 4 B per lane).
+// MFMA k index q of step s in source tile i <-> column 16 i + 4 q + s, so a lane's operands are the 16-byte
+// groups both tensors are stored in.  Same arithmetic as lstm_scan_bwd_kernel up to the order of the sums.
+// ------------------------------------------------------------------------------------------------
+#define L2D_R 8
+__global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A) {
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TW = A.KS / (4 * L2D_R);                  // source tiles per wave (1..4)
+    float* Wb = smem;                                   // [4 waves][TW][2 unit tiles][64][4]
+    float* red2 = Wb + (size_t)TW * 2048;               // [4 waves][2][64][4]
+    float* scr = red2 + 2048;                           // combine_sums scratch
+    int* flag = (int*)(scr + 256);
+
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
+    const int grp = chunk * A.ndir + dir;
+    const LstmDir& D = A.d[dir];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, bl = lane & 15;
+    const int b = chunk * 16 + bl;
+    const bool bvalid = b < A.B;
+    const int N = A.N, KS = A.KS, T = A.T, B = A.B, G = A.G;
+    const int ub = j / L2D_R, kr = j % L2D_R;
+
+    GroupSync gs;
+    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
+    {
+        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * TW * 2048);
+        f32x4* dst = (f32x4*)Wb;
+        for (int i = tid; i < TW * 512; i += 256) dst[i] = src[i];
+    }
+    // exchange buffers inside the (larger) dex region: dhx [2][KS tiles][16 b][16 cols], px [2][G][2][16 b][16 u]
+    float* dhx = A.dex + (size_t)grp * 2 * KS * G * 64;
+    float* px = dhx + (size_t)2 * KS * 256;
+    float* sta = A.sta + (size_t)grp * 2 * KS * 128;
+    float* stc = A.stc ? A.stc + (size_t)grp * 2 * KS * 32 : nullptr;
+    const __amdgpu_buffer_rsrc_t dhx_rs = make_rsrc_(dhx, (unsigned)((size_t)2 * KS * 256 * 4));
+    const __amdgpu_buffer_rsrc_t px_rs = make_rsrc_(px, (unsigned)((size_t)2 * G * 512 * 4));
+
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool own = wv == 0;
+    const int tile = j, unit = tile * 4 + q, col4 = unit * 4;
+    float ac_u = 1.f, bc_u = 0.f;
+    if (A.cell_ln) { ac_u = D.alpha_c[unit]; bc_u = D.beta_c[unit]; }
+    float dc = 0.f, dr_pass = 0.f;
+    f32x4 al4 = {1.f, 1.f, 1.f, 1.f};
+    if (own) al4 = *(const f32x4*)(D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4);
+    __syncthreads();
+
+    const bool cln = own && A.cell_ln;
+    const int bq = bvalid ? b : (B - 1);
+    const float* const dummy = D.wpack;
+    const int dt = D.reverse ? 1 : -1;
+    auto row_of = [&](int k) { k = k < T ? k : T - 1; return (size_t)(D.reverse ? k : T - 1 - k) * B + bq; };
+    const size_t r00 = row_of(0);
+    const float* p_m = own ? A.mask + (size_t)bq * A.msb + (size_t)(D.reverse ? 0 : T - 1) * A.mst : dummy;
+    const float* p_g = own ? D.gates + r00 * 4 * N + col4 : dummy;
+    const float* p_dr = own ? D.dr_ext + r00 * D.ld_dr + unit : dummy;
+    const float* p_ah = own ? D.ahat + r00 * 4 * N + col4 : dummy;
+    const float* p_ra = D.rs_a + r00;                                   // every lane: rstd of row bl
+    const float* p_ch = cln ? D.chat + r00 * N + unit : dummy;
+    const float* p_rc = cln ? D.rs_c + r00 : dummy;
+    const float* p_c2 = own ? D.cst + row_of(2) * N + unit : dummy;
+    // ahat of this member's column slice, row bl: source tile kr*(KS/8) + wave*TW + i, columns 4q..4q+3 of it
+    const float* p_as = D.ahat + r00 * 4 * N + (size_t)(kr * (KS / L2D_R) + wv * TW) * 16 + 4 * q;
+    const int s_m = own ? dt * A.mst : 0, s_g = own ? dt * B * 4 * N : 0, s_dr = own ? dt * B * D.ld_dr : 0;
+    const int s_ah = own ? dt * B * 4 * N : 0, s_ra = dt * B, s_as = dt * B * 4 * N;
+    const int s_ch = cln ? dt * B * N : 0, s_rc = cln ? dt * B : 0, s_c = own ? dt * B * N : 0;
+    float c0v = *(own ? D.cst + row_of(0) * N + unit : dummy), c1v = *(own ? D.cst + row_of(1) * N + unit : dummy);
+    const float c_init = *((own && D.c0) ? D.c0 + (size_t)bq * N + unit : dummy);
+    const bool has_c0 = D.c0 != nullptr;
+    float n_m, n_dre, n_ra, n_ch, n_rc, n_c2;
+    f32x4 n_g4, n_ah4, n_as[4];
+    auto prefetch = [&]() {
+        n_m = *p_m; n_g4 = *(const f32x4*)p_g; n_dre = *p_dr;
+        n_ah4 = *(const f32x4*)p_ah; n_ra = *p_ra;
+        n_ch = *p_ch; n_rc = *p_rc; n_c2 = *p_c2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n_as[i] = *(const f32x4*)(p_as + (i < TW ? i : 0) * 16);
+    };
+    prefetch();
+    float* q_dg = D.dG + r00 * 4 * N + col4;
+    float* q_da = D.dA ? D.dA + r00 * 4 * N + col4 : nullptr;
+    float* q_do = (A.cell_ln && D.dOut) ? D.dOut + r00 * N + unit : nullptr;
+    const int z_dg = dt * B * 4 * N, z_da = q_da ? dt * B * 4 * N : 0, z_do = q_do ? dt * B * N : 0;
+    // own units inside the block: unit tile kr >> 2, units 4*(kr&3) .. +3
+    const unsigned px_own = (unsigned)((((kr >> 2) * 16 + bl) * 16 + 4 * (kr & 3) + q) * 4);
+
+    for (int step = 0; step < T; ++step) {
+        const int st = T - 1 - step;
+        const int par = step & 1;
+        const bool live = own && bvalid;
+        const float m = live ? n_m : 0.f;
+        const f32x4 g4 = n_g4, ah4 = n_ah4;
+        f32x4 as4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) as4[i] = n_as[i];
+        const float c_new = c0v, c_prev = st > 0 ? c1v : (has_c0 ? c_init : 0.f);
+        const float dre = live ? n_dre : 0.f, rs_a = n_ra, chat_v = n_ch, rs_c = n_rc;
+        {
+            const bool go = step + 1 < T;
+            p_m += go ? s_m : 0; p_g += go ? s_g : 0; p_dr += go ? s_dr : 0; p_ah += go ? s_ah : 0;
+            p_ra += go ? s_ra : 0; p_as += go ? s_as : 0; p_ch += go ? s_ch : 0; p_rc += go ? s_rc : 0;
+            prefetch();
+            p_c2 += (step + 3 < T) ? s_c : 0;
+        }
+        // 1. the 8 members' partials of the own 4 units, published by the previous backward step
+        float dr_sum = 0.f;
+        if (step > 0) {
+            if (!group_wait(gs)) break;
+            float v[L2D_R];
+#pragma unroll
+            for (int s_ = 0; s_ < L2D_R; ++s_)
+                v[s_] = ldb_sc1(px_rs, px_own, (unsigned)((((size_t)(par ^ 1) * G + ub * L2D_R + s_) * 512) * 4));
+#pragma unroll
+            for (int s_ = 0; s_ < L2D_R; ++s_) dr_sum += v[s_];
+        }
+        // 2. cell / gate gradients (as lstm_scan_bwd_kernel)
+        const float dr_t = dre + dr_pass + dr_sum;
+        const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3];
+        const bool on = (m != 0.f);
+        float outcell = c_new;
+        if (A.cell_ln) outcell = ac_u * chat_v + bc_u;
+        const float tc = tanhf_(outcell);
+        float do_ = 0.f, dout = 0.f;
+        if (on) {
+            do_ = dr_t * tc;
+            dout = clipf_(dr_t * og * (1.f - tc * tc), A.clip);
+        }
+        float dcn = dout;
+        if (A.cell_ln) {
+            const float dxh = dout * ac_u;
+            if (own) {
+                const float s1 = sum_q(dxh), s2 = sum_q(dxh * chat_v);
+                if (q == 0) st_sc1_f2(stc + ((size_t)par * KS + tile) * 32 + bl * 2, s1, s2);
+            }
+            group_publish(gs);
+            if (own && bvalid && q_do) *q_do = dout;
+            if (!group_wait(gs)) break;
+            {
+                float s1, s2;
+                combine_sums(stc + (size_t)par * KS * 32, KS, tid, s1, s2, scr);
+                dcn = rs_c * (dxh - s1 / N - chat_v * (s2 / N));
+            }
+        }
+        f32x4 dg4 = {0, 0, 0, 0};
+        if (on) {
+            const float dct = dc + dcn;
+            dg4[0] = clipf_(dct * gg * ig * (1.f - ig), A.clip);
+            dg4[1] = clipf_(dct * c_prev * fg * (1.f - fg), A.clip);
+            dg4[2] = clipf_(dct * ig * (1.f - gg * gg), A.clip);
+            dg4[3] = clipf_(do_ * og * (1.f - og), A.clip);
+            dc = dct * fg;
+            dr_pass = 0.f;
+        } else {
+            dr_pass = dr_t;
+        }
+        // 3. gate-LN statistics + all-gather of dah
+        const f32x4 dah = own ? dg4 * al4 : f32x4{0, 0, 0, 0};
+        if (own) {
+            const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
+            const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
+            if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 128 + bl * 2, s1, s2);
+            st_sc1_f4(dhx_rs, (unsigned)((((size_t)par * KS + tile) * 256 + bl * 16 + q * 4) * 4), dah);
+        }
+        group_publish(gs);
+        if (own && bvalid) *(f32x4*)q_dg = dg4;
+        if (!group_wait(gs)) break;
+        float s1, s2;
+        combine_sums(sta + (size_t)par * KS * 128, KS, tid, s1, s2, scr, 128);
+        const float m1 = s1 / (4 * N), m2 = s2 / (4 * N);
+        const f32x4 da4 = rs_a * (dah - m1 - ah4 * m2);                  // own columns (owner wave)
+        // 4. partial dr_{t-1} of the block's 32 units over this member's column slice
+        if (step + 1 < T) {
+            f32x4 dv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dv[i] = ldb_sc1_f4(dhx_rs, (unsigned)((bl * 16 + q * 4) * 4),
+                                   (unsigned)((((size_t)par * KS + kr * (KS / L2D_R) + wv * TW + (i < TW ? i : 0)) * 256) * 4));
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < TW) {
+                    const f32x4 dai = rs_a * (dv[i] - m1 - as4[i] * m2);
+                    const f32x4 w0 = *(const f32x4*)(Wb + ((((size_t)wave * TW + i) * 2 + 0) * 64 + lane) * 4);
+                    const f32x4 w1 = *(const f32x4*)(Wb + ((((size_t)wave * TW + i) * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = mfma4(w0[e], dai[e], acc0);
+                        acc1 = mfma4(w1[e], dai[e], acc1);
+                    }
+                }
+            }
+            *(f32x4*)(red2 + (((size_t)wave * 2 + 0) * 64 + lane) * 4) = acc0;
+            *(f32x4*)(red2 + (((size_t)wave * 2 + 1) * 64 + lane) * 4) = acc1;
+            __syncthreads();
+            if (wave < 2) {                              // unit tile `wave`: lane (q, bl) = units 4q..4q+3, batch bl
+                f32x4 v = *(const f32x4*)(red2 + (((size_t)0 * 2 + wave) * 64 + lane) * 4);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red2 + (((size_t)w * 2 + wave) * 64 + lane) * 4);
+                st_sc1_f4(px_rs, (unsigned)(((((size_t)par * G + j) * 2 + wave) * 256 + bl * 16 + q * 4) * 4), v);
+            }
+            group_publish(gs);
+        }
+        if (own && bvalid && q_da) *(f32x4*)q_da = da4;
+        c0v = c1v; c1v = n_c2;
+        q_dg += z_dg; q_da += z_da; q_do += z_do;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------------
 struct asr_lstm_scan_desc {      // mirrored in include/asr_amd.h
@@ -1026,8 +1264,10 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     size_t lds;
     // cell-LN nets at UT = 1, N <= 512: the forward kernel with one exchange fewer per step
     const bool fused_cln = !backward && A.cell_ln && UT == 1 && A.KSP / 16 <= 8;
-    if (!backward) lds = ((size_t)UT * A.KSP * 64 + UT * 4 * 256) * 4 + 64 + (fused_cln ? 1024 : 0);
-    else lds = ((size_t)UT * A.KT * 256 + UT * 256 + UT * 1024) * 4 + 64;
+    lds = ((size_t)UT * A.KSP * 64 + UT * 4 * 256) * 4 + 64 + (fused_cln ? 1024 : 0);
+    const bool ln2d = backward && UT == 1 && asr_lstm_bwd_pack_mode(d->N, d->ndir, d->ln_kind) == 2;
+    if (ln2d) lds = ((size_t)(A.KS / 32) * 2048 + 2048 + 256) * 4 + 64;
+    else if (backward) lds = ((size_t)UT * A.KT * 256 + UT * 256 + UT * 1024) * 4 + 64;
     if (lds > 160 * 1024) return ASR_ERR_ARG;
     // one workgroup per CU (what the sc1 hand-off is measured for, MI355X_MICROARCH.md 'Valid forms'): a launch
     // never exceeds 256 workgroups, so asking for more than half of a CU's 160 KB spreads them one per CU
@@ -1049,7 +1289,10 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
             } else if (UT == 1) LAUNCH_(lstm_scan_fwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_fwd_kernel, 2);
             else LAUNCH_(lstm_scan_fwd_kernel, 4);
         } else {
-            if (UT == 1) LAUNCH_(lstm_scan_bwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_bwd_kernel, 2);
+            if (ln2d) {
+                hipFuncSetAttribute((const void*)lstm_scan_bwd_ln2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(lstm_scan_bwd_ln2d_kernel, grid, block, lds, stream, Al);
+            } else if (UT == 1) LAUNCH_(lstm_scan_bwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_bwd_kernel, 2);
             else LAUNCH_(lstm_scan_bwd_kernel, 4);
         }
 #undef LAUNCH_

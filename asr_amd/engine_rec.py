@@ -171,8 +171,9 @@ class RecPair(object):
                 Wf = dp.p('Wh')
             c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d), L.asr_lstm_pack_floats(N, 0)))
             if train:
-                c['wpkb'] = ops.lstm_pack(Wf, N, 1, net.arena.get('L%d.wpkb%d' % (self.idx, d),
-                                                                  L.asr_lstm_pack_floats(N, 1)))
+                pm = L.asr_lstm_bwd_pack_mode(N, self.ndir, self.ln_kind + (2 if self.grp == 4 else 0))
+                c['wpkb'] = ops.lstm_pack(Wf, N, pm, net.arena.get('L%d.wpkb%d' % (self.idx, d),
+                                                                   L.asr_lstm_pack_floats(N, pm)))
             Dd = desc.dir[d]
             Dd.reverse = 1 if self.reverse[d] else 0
             Dd.xin = xin.data_ptr(); Dd.wpack = c['wpk'].data_ptr()

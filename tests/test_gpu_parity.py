@@ -296,6 +296,24 @@ def test_projection_hyper_small(clip):
         assert relerr(got, onet.layers[0][d].inner_hid) < 2e-5
 
 
+@pytest.mark.parametrize('kind', ['ln', 'icond'])
+def test_ln_backward_2d_decomposition_n128(kind):
+    """N = 128 (32 workgroups per direction, one source tile per wave): the row-LN backward runs as
+    lstm_scan_bwd_ln2d_kernel (asr_lstm_bwd_pack_mode == 2); B = 18 adds a second, ragged batch chunk."""
+    from asr_amd import _lib, gating_hyper_nets as G
+    assert _lib.lib().asr_lstm_bwd_pack_mode(128, 2, 1) == 2 and _lib.lib().asr_lstm_bwd_pack_mode(8, 2, 1) == 1
+    cond_key = None
+    if kind == 'ln':
+        net = G.deep_projection_ln_lstm_model(None, None, 11, 13, 2, None, 128, 1.0, 0.0, device=_dev(), seed=81)
+    else:
+        net, _ = G.deep_projection_ivector_ln_model(None, None, None, 11, 13, 2, 1, 16, 128, 1.0, 0.0, cond_dim=7,
+                                                    device=_dev(), seed=82)
+        cond_key = 'ivec'
+    perturb_params(net, 83, 0.03)
+    b = make_batch(np.random.default_rng(84), 18, 23, 11, 13, I=7 if cond_key else 0)
+    run_case(net, b, cond_key=cond_key, calibrate=True)
+
+
 def test_projection_hyper_aux_costs_and_trainer():
     """scripts/hypernets/exp_prj_hyper.py:70-146: the inter / intra variance costs on the inner hidden sequences
     and their gradient through the whole net, against the oracle (weights 0.7 / 1.3); then the trainer's outputs."""
