@@ -102,11 +102,11 @@ extern "C" size_t asr_lstm_pack_floats(int N, int mode) {
     return mode == 0 ? (size_t)KS * KSP * 64 : mode == 1 ? (size_t)KS * KT * 256 : (size_t)KS * (KS / 32) * 2048;
 }
 
-// Which packing the backward scan of a layer expects (1 or 2): 2 = the 2-D decomposition, taken for row-LN
-// variants (ln_kind 1 / 2) whose grid is one workgroup per 4 units (N/4 * ndir <= 256) with N a multiple of 128,
+// Which packing the backward scan of a layer expects (1 or 2): 2 = the 2-D decomposition, taken for the LN
+// variants (ln_kind 1..4) whose grid is one workgroup per 4 units (N/4 * ndir <= 256) with N a multiple of 128,
 // N <= 512.  The caller packs W with this mode and the launcher selects the kernel by the same rule.
 extern "C" int asr_lstm_bwd_pack_mode(int N, int ndir, int ln_kind) {
-    if ((ln_kind == 1 || ln_kind == 2) && N > 0 && N % 128 == 0 && N <= 512 && ndir >= 1 && (N / 4) * ndir <= 256)
+    if (ln_kind >= 1 && ln_kind <= 4 && N > 0 && N % 128 == 0 && N <= 512 && ndir >= 1 && (N / 4) * ndir <= 256)
         return 2;
     return 1;
 }
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, row-LN variants (ln_kind 1 / 2, not per gate) at UT = 1 with G = N/4 a multiple of 32 and N <= 512:
+// backward, LN variants (row or per-gate statistics) at UT = 1 with G = N/4 a multiple of 32 and N <= 512:
 // the dr_{t-1} = da . W'^T product as a 2-D decomposition instead of the all-to-all of per-destination
 // partials (32 KB written and 32 KB read per workgroup and step).  Workgroup j = (unit block ub = j / 8,
 // member kr = j % 8):
@@ -1027,23 +1027,25 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
     const float* p_g = own ? D.gates + r00 * 4 * N + col4 : dummy;
     const float* p_dr = own ? D.dr_ext + r00 * D.ld_dr + unit : dummy;
     const float* p_ah = own ? D.ahat + r00 * 4 * N + col4 : dummy;
-    const float* p_ra = D.rs_a + r00;                                   // every lane: rstd of row bl
+    const int rsw = A.per_gate ? 4 : 1;
+    const float* p_ra = D.rs_a + r00 * rsw;                             // every lane: rstd of row bl (x4 per gate)
     const float* p_ch = cln ? D.chat + r00 * N + unit : dummy;
     const float* p_rc = cln ? D.rs_c + r00 : dummy;
     const float* p_c2 = own ? D.cst + row_of(2) * N + unit : dummy;
     // ahat of this member's column slice, row bl: source tile kr*(KS/8) + wave*TW + i, columns 4q..4q+3 of it
     const float* p_as = D.ahat + r00 * 4 * N + (size_t)(kr * (KS / L2D_R) + wv * TW) * 16 + 4 * q;
     const int s_m = own ? dt * A.mst : 0, s_g = own ? dt * B * 4 * N : 0, s_dr = own ? dt * B * D.ld_dr : 0;
-    const int s_ah = own ? dt * B * 4 * N : 0, s_ra = dt * B, s_as = dt * B * 4 * N;
+    const int s_ah = own ? dt * B * 4 * N : 0, s_ra = dt * B * rsw, s_as = dt * B * 4 * N;
     const int s_ch = cln ? dt * B * N : 0, s_rc = cln ? dt * B : 0, s_c = own ? dt * B * N : 0;
     float c0v = *(own ? D.cst + row_of(0) * N + unit : dummy), c1v = *(own ? D.cst + row_of(1) * N + unit : dummy);
     const float c_init = *((own && D.c0) ? D.c0 + (size_t)bq * N + unit : dummy);
     const bool has_c0 = D.c0 != nullptr;
-    float n_m, n_dre, n_ra, n_ch, n_rc, n_c2;
-    f32x4 n_g4, n_ah4, n_as[4];
+    float n_m, n_dre, n_ch, n_rc, n_c2;
+    f32x4 n_g4, n_ah4, n_as[4], n_ra4;
     auto prefetch = [&]() {
         n_m = *p_m; n_g4 = *(const f32x4*)p_g; n_dre = *p_dr;
-        n_ah4 = *(const f32x4*)p_ah; n_ra = *p_ra;
+        n_ah4 = *(const f32x4*)p_ah;
+        if (A.per_gate) n_ra4 = *(const f32x4*)p_ra; else { const float r1_ = *p_ra; n_ra4 = f32x4{r1_, r1_, r1_, r1_}; }
         n_ch = *p_ch; n_rc = *p_rc; n_c2 = *p_c2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) n_as[i] = *(const f32x4*)(p_as + (i < TW ? i : 0) * 16);
@@ -1066,7 +1068,8 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
 #pragma unroll
         for (int i = 0; i < 4; ++i) as4[i] = n_as[i];
         const float c_new = c0v, c_prev = st > 0 ? c1v : (has_c0 ? c_init : 0.f);
-        const float dre = live ? n_dre : 0.f, rs_a = n_ra, chat_v = n_ch, rs_c = n_rc;
+        const float dre = live ? n_dre : 0.f, chat_v = n_ch, rs_c = n_rc;
+        const f32x4 rs_a = n_ra4;                        // per gate (row LN: the same value four times)
         {
             const bool go = step + 1 < T;
             p_m += go ? s_m : 0; p_g += go ? s_g : 0; p_dr += go ? s_dr : 0; p_ah += go ? s_ah : 0;
@@ -1128,17 +1131,34 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
         // 3. gate-LN statistics + all-gather of dah
         const f32x4 dah = own ? dg4 * al4 : f32x4{0, 0, 0, 0};
         if (own) {
-            const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
-            const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
-            if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 128 + bl * 2, s1, s2);
+            if (!A.per_gate) {
+                const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
+                const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
+                if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 128 + bl * 2, s1, s2);
+            } else {
+                f32x4 s14, s24;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { s14[g] = sum_q(dah[g]); s24[g] = sum_q(dah[g] * ah4[g]); }
+                const float s1q = q == 0 ? s14[0] : q == 1 ? s14[1] : q == 2 ? s14[2] : s14[3];
+                const float s2q = q == 0 ? s24[0] : q == 1 ? s24[1] : q == 2 ? s24[2] : s24[3];
+                st_sc1_f2(sta + (((size_t)par * KS + tile) * 4 + q) * 32 + bl * 2, s1q, s2q);
+            }
             st_sc1_f4(dhx_rs, (unsigned)((((size_t)par * KS + tile) * 256 + bl * 16 + q * 4) * 4), dah);
         }
         group_publish(gs);
         if (own && bvalid) *(f32x4*)q_dg = dg4;
         if (!group_wait(gs)) break;
-        float s1, s2;
-        combine_sums(sta + (size_t)par * KS * 128, KS, tid, s1, s2, scr, 128);
-        const float m1 = s1 / (4 * N), m2 = s2 / (4 * N);
+        f32x4 m1, m2;                                    // per gate = per column % 4 = per element of a lane's group
+        if (!A.per_gate) {
+            float s1, s2;
+            combine_sums(sta + (size_t)par * KS * 128, KS, tid, s1, s2, scr, 128);
+            const float a_ = s1 / (4 * N), b_ = s2 / (4 * N);
+            m1 = f32x4{a_, a_, a_, a_}; m2 = f32x4{b_, b_, b_, b_};
+        } else {
+            f32x4 s14, s24;
+            combine_sums4(sta + (size_t)par * KS * 128, KS, tid, s14, s24, scr);
+            m1 = s14 * (1.0f / N); m2 = s24 * (1.0f / N);
+        }
         const f32x4 da4 = rs_a * (dah - m1 - ah4 * m2);                  // own columns (owner wave)
         // 4. partial dr_{t-1} of the block's 32 units over this member's column slice
         if (step + 1 < T) {

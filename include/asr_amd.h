@@ -151,7 +151,7 @@ typedef struct asr_lstm_scan_desc {
 
 size_t asr_lstm_pack_floats(int N, int mode);
 int asr_lstm_pack_w(const float* W, int N, int mode, float* out, asr_stream_t stream);
-/* Packing the backward scan of a layer expects for W (mode of asr_lstm_pack_w): 1, or 2 for the row-LN variants
+/* Packing the backward scan of a layer expects for W (mode of asr_lstm_pack_w): 1, or 2 for the LN variants (ln_kind 1..4)
  * whose backward runs as the 2-D decomposition (N % 128 == 0, N <= 512, N/4 * ndir <= 256).  Pack with the mode
  * this returns; asr_lstm_scan_bwd selects its kernel by the same rule. */
 int asr_lstm_bwd_pack_mode(int N, int ndir, int ln_kind);

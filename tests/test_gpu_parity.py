@@ -296,7 +296,7 @@ def test_projection_hyper_small(clip):
         assert relerr(got, onet.layers[0][d].inner_hid) < 2e-5
 
 
-@pytest.mark.parametrize('kind', ['ln', 'icond'])
+@pytest.mark.parametrize('kind', ['ln', 'icond', 'gate_ln', 'sample_gate_ln'])
 def test_ln_backward_2d_decomposition_n128(kind):
     """N = 128 (32 workgroups per direction, one source tile per wave): the row-LN backward runs as
     lstm_scan_bwd_ln2d_kernel (asr_lstm_bwd_pack_mode == 2); B = 18 adds a second, ragged batch chunk."""
@@ -305,6 +305,12 @@ def test_ln_backward_2d_decomposition_n128(kind):
     cond_key = None
     if kind == 'ln':
         net = G.deep_projection_ln_lstm_model(None, None, 11, 13, 2, None, 128, 1.0, 0.0, device=_dev(), seed=81)
+    elif kind == 'gate_ln':                 # per-gate statistics (LayerNormProjectLSTM_v0_2_Layer)
+        net = G.deep_prj_lstm_ln_model_v2(None, None, 11, 13, 2, 128, 64, grad_clipping=1.0, device=_dev(), seed=85)
+    elif kind == 'sample_gate_ln':          # CondLayerNormProjectLSTM_v0_2_Layer
+        out = G.deep_prj_lstm_dln_model_v2(None, None, 11, 13, 128, 64, 16, 2, num_conds=1, grad_clipping=1.0,
+                                           device=_dev(), seed=86)
+        net = out[0] if isinstance(out, (tuple, list)) else out
     else:
         net, _ = G.deep_projection_ivector_ln_model(None, None, None, 11, 13, 2, 1, 16, 128, 1.0, 0.0, cond_dim=7,
                                                     device=_dev(), seed=82)
