@@ -235,7 +235,7 @@ extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, floa
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int tiles = ntm * ntn;
     int ns = 1;
-    if (ws && tiles < 768 && K >= 2048) {                    // fewer than 3 workgroups per CU: split K so
+    if (ws && ((tiles < 768 && K >= 2048) || (tiles < 256 && K >= 512))) {   // (TBPTT windows: M = 1600 rows, K = 1600)                    // fewer than 3 workgroups per CU: split K so
         ns = (1024 + tiles / 2) / tiles;                     // that ~4 per CU are in flight (a 128-tile
                                                              // dW_x ran on half the chip: 40 TFLOP/s)
         const int maxk = K / (BK * 8);                       // at least 8 K-tiles per split

@@ -973,7 +973,8 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
 // groups both tensors are stored in.  Same arithmetic as lstm_scan_bwd_kernel up to the order of the sums.
 // ------------------------------------------------------------------------------------------------
 #define L2D_R 8
-__global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A) {
+template <int PG>                                       // PG: per-gate LN statistics (compile time: the row-LN
+__global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A) {   // path keeps scalar statistics)
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TW = A.KS / (4 * L2D_R);                  // source tiles per wave (1..4)
@@ -1027,7 +1028,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
     const float* p_g = own ? D.gates + r00 * 4 * N + col4 : dummy;
     const float* p_dr = own ? D.dr_ext + r00 * D.ld_dr + unit : dummy;
     const float* p_ah = own ? D.ahat + r00 * 4 * N + col4 : dummy;
-    const int rsw = A.per_gate ? 4 : 1;
+    const int rsw = PG ? 4 : 1;
     const float* p_ra = D.rs_a + r00 * rsw;                             // every lane: rstd of row bl (x4 per gate)
     const float* p_ch = cln ? D.chat + r00 * N + unit : dummy;
     const float* p_rc = cln ? D.rs_c + r00 : dummy;
@@ -1045,7 +1046,8 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
     auto prefetch = [&]() {
         n_m = *p_m; n_g4 = *(const f32x4*)p_g; n_dre = *p_dr;
         n_ah4 = *(const f32x4*)p_ah;
-        if (A.per_gate) n_ra4 = *(const f32x4*)p_ra; else { const float r1_ = *p_ra; n_ra4 = f32x4{r1_, r1_, r1_, r1_}; }
+        if (PG) n_ra4 = *(const f32x4*)p_ra;
+        else { const float r1_ = *p_ra; n_ra4 = f32x4{r1_, r1_, r1_, r1_}; }
         n_ch = *p_ch; n_rc = *p_rc; n_c2 = *p_c2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) n_as[i] = *(const f32x4*)(p_as + (i < TW ? i : 0) * 16);
@@ -1131,7 +1133,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
         // 3. gate-LN statistics + all-gather of dah
         const f32x4 dah = own ? dg4 * al4 : f32x4{0, 0, 0, 0};
         if (own) {
-            if (!A.per_gate) {
+            if (!PG) {
                 const float s1 = sum_q(dah[0] + dah[1] + dah[2] + dah[3]);
                 const float s2 = sum_q(dah[0] * ah4[0] + dah[1] * ah4[1] + dah[2] * ah4[2] + dah[3] * ah4[3]);
                 if (q == 0) st_sc1_f2(sta + ((size_t)par * KS + tile) * 128 + bl * 2, s1, s2);
@@ -1149,7 +1151,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
         if (own && bvalid) *(f32x4*)q_dg = dg4;
         if (!group_wait(gs)) break;
         f32x4 m1, m2;                                    // per gate = per column % 4 = per element of a lane's group
-        if (!A.per_gate) {
+        if (!PG) {
             float s1, s2;
             combine_sums(sta + (size_t)par * KS * 128, KS, tid, s1, s2, scr, 128);
             const float a_ = s1 / (4 * N), b_ = s2 / (4 * N);
@@ -1310,8 +1312,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
             else LAUNCH_(lstm_scan_fwd_kernel, 4);
         } else {
             if (ln2d) {
-                hipFuncSetAttribute((const void*)lstm_scan_bwd_ln2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(lstm_scan_bwd_ln2d_kernel, grid, block, lds, stream, Al);
+                if (A.per_gate) LAUNCH_(lstm_scan_bwd_ln2d_kernel, 1); else LAUNCH_(lstm_scan_bwd_ln2d_kernel, 0);
             } else if (UT == 1) LAUNCH_(lstm_scan_bwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_bwd_kernel, 2);
             else LAUNCH_(lstm_scan_bwd_kernel, 4);
         }
