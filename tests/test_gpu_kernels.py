@@ -134,3 +134,30 @@ def test_softmax_ce_kernel():
     assert (pred.cpu().numpy() == p).all()
     assert relerr(dl.cpu().numpy().reshape(T, B, C).transpose(1, 0, 2), dlo) < 1e-5
     assert np.max(np.abs(out.cpu().numpy() - O.log_softmax(lgb))) < 2e-5
+
+
+def test_lstm_pack_modes_against_their_definitions():
+    """asr_lstm_pack_w modes 1 and 2 (asr_amd/csrc/scan_lstm.hip header comments), N = 128."""
+    from asr_amd import _lib, ops
+    N = 128
+    KS = N // 4; KT = N // 16; TW = KS // 32
+    rng = np.random.default_rng(5)
+    W = rng.standard_normal((N, 4 * N)).astype(np.float32)
+    Wd = torch.from_numpy(W).cuda()
+    L = _lib.lib()
+    for mode in (1, 2):
+        n = L.asr_lstm_pack_floats(N, mode)
+        out = torch.zeros(n, device='cuda')
+        ops.lstm_pack(Wd, N, mode, out)
+        got = out.cpu().numpy()
+        if mode == 1:
+            tile, kt, l, e = np.meshgrid(np.arange(KS), np.arange(KT), np.arange(64), np.arange(4), indexing='ij')
+            want = W[kt * 16 + (l & 15), tile * 16 + 4 * e + (l >> 4)]
+        else:
+            j, w, i, t, l, e = np.meshgrid(np.arange(KS), np.arange(4), np.arange(TW), np.arange(2), np.arange(64),
+                                           np.arange(4), indexing='ij')
+            ub, kr = j // 8, j % 8
+            want = W[ub * 32 + t * 16 + (l & 15), 16 * (kr * (KS // 8) + w * TW + i) + 4 * (l >> 4) + e]
+        assert n == want.size
+        assert np.array_equal(got, want.reshape(-1))
+    assert L.asr_lstm_pack_w(Wd.data_ptr(), 8, 2, out.data_ptr(), None) == -1          # mode 2 needs N % 128 == 0
