@@ -235,7 +235,10 @@ extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, floa
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int tiles = ntm * ntn;
     int ns = 1;
-    if (ws && ((tiles < 768 && K >= 2048) || (tiles < 256 && K >= 512))) {   // (TBPTT windows: M = 1600 rows, K = 1600)                    // fewer than 3 workgroups per CU: split K so
+    // second clause: the small problems of a TBPTT window (M = 1600 rows or K = 1600); kept to M <= 2048 so that the
+    // forward GEMMs of whole utterance batches are never split (their K is 123..1024): a row's posteriors then do
+    // not depend, even by rounding, on how many rows share the batch (tests/test_gpu_fullsize.py)
+    if (ws && ((tiles < 768 && K >= 2048) || (tiles < 256 && K >= 512 && M <= 2048))) {                    // fewer than 3 workgroups per CU: split K so
         ns = (1024 + tiles / 2) / tiles;                     // that ~4 per CU are in flight (a 128-tile
                                                              // dW_x ran on half the chip: 40 TFLOP/s)
         const int maxk = K / (BK * 8);                       // at least 8 K-tiles per split
