@@ -215,7 +215,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     const size_t tot = (size_t)M * N;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
         float acc = 0.f;
-        for (int s = 0; s < ns; ++s) acc += part[(size_t)s * tot + i];
+        int s = 0;
+        for (; s + 8 <= ns; s += 8) {                   // 8 partials in flight, summed in split order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(s + k) * tot + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; s < ns; ++s) acc += part[(size_t)s * tot + i];
         const int row = (int)(i / N), col = (int)(i % N);
         float* p = C + (size_t)row * ldc + col;
         float v = alpha * acc + (bias ? bias[col] : 0.f);
