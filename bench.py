@@ -4,7 +4,9 @@ bidirectional, C=3436, B=16 per GPU, two concatenated WSJ-shaped utterances per 
 1.0) -- forward + BPTT + gradient all-reduce + Adam, data already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of the gradients)
+  N > 1: one rank per GPU, RCCL all-reduce of the gradients.  Under torch.distributed.run (WORLD_SIZE
+  set) this process IS a rank; started plainly it spawns the N ranks itself as child processes before
+  anything touches the GPU, relays rank 0's JSON line and exits non-zero if a rank fails.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the persistent HyperLSTM
 BPTT scan), timed live with HIP events on the launch stream; `cpu_baseline` is the numpy oracle
@@ -58,6 +60,118 @@ def cpu_baseline(net, sample_len=640):      # ~10 s of host work on the GPU box'
                        '(%d frames, %.1f s)' % (BATCH, sample_len, b['frames'], dt))
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children.  The
+    parent never initialises the GPU (no torch.cuda call), it only relays rank 0's output."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
+               LOCAL_WORLD_SIZE=str(args.gpus))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed: %r\n' % (bad,))
+        return 1
+    return 0
+
+
+class StepClock(object):
+    """Per-step durations without host syncs: one event pair per step on the launch stream (wall clock
+    on the CPU self-test).  The headline `value` stays total frames / total bracketed wall time; the
+    median of the per-step rates is reported beside it."""
+    def __init__(self, cuda):
+        self.cuda = cuda
+        self.ev = []
+
+    def start(self):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True); e.record(); self._e0 = e
+        else:
+            self._e0 = time.time()
+
+    def stop(self, frames):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True); e.record()
+            self.ev.append((self._e0, e, frames))
+        else:
+            self.ev.append((self._e0, time.time(), frames))
+
+    def summary(self):
+        if self.cuda:
+            ms = np.array([a.elapsed_time(b) for a, b, _ in self.ev])
+        else:
+            ms = np.array([(b - a) * 1e3 for a, b, _ in self.ev])
+        fr = np.array([f for _, _, f in self.ev], dtype=np.float64)
+        return dict(ms_per_step_median=float(np.median(ms)), ms_per_step_min=float(ms.min()),
+                    ms_per_step_max=float(ms.max()),
+                    frames_per_s_median_step=float(np.median(fr / (ms * 1e-3))))
+
+
+def selftest_cpu(args, rank, world):
+    """CPU rehearsal of the N-rank protocol (tests/test_host.py): gloo, no kernels.  Every rank fills a
+    flat gradient of a tiny network's size, the per-layer buckets go through dp.GradAllReduce exactly
+    as Network.backward() hands them over (reverse topological order), the timed region is bracketed
+    as in the real run.  The printed line is marked selftest: its value measures nothing."""
+    import torch.distributed as dist
+    from asr_amd import dp
+    from asr_amd.builders import build_deep_hyperlstm
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    net = build_deep_hyperlstm('hyper', None, None, 5, 2, 8, 4, 2, 6, 1.0, True, 0, device='cpu', seed=1)
+    ar = dp.GradAllReduce(net)
+    assert ar.world == world == args.gpus, (ar.world, world, args.gpus)
+    ranges = [net.param_range('out.')] + [net.param_range('L%d.' % i) for i in range(len(net.pairs) - 1, -1, -1)]
+    clock = StepClock(False)
+
+    def step(i):
+        net.store.g.fill_(float(rank + 1))
+        for lo, hi in ranges:
+            if net.grad_hook:
+                net.grad_hook(lo, hi)
+        ar.finish()
+        want = world * (world + 1) / 2.0
+        assert float(net.store.g.min()) == want == float(net.store.g.max())
+        return 100
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    t0 = time.time(); frames = 0
+    for i in range(args.steps):
+        clock.start(); f = step(i); clock.stop(f); frames += f
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = tt.item()
+        ff = torch.tensor([float(frames)], dtype=torch.float64); dist.all_reduce(ff); frames = ff.item()
+    if rank == 0:
+        out = dict(metric='train frames/sec (node) 4x512 HyperLSTM', selftest=True, value=frames / dt,
+                   unit='frames/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='f32', data='synthetic',
+                   config=dict(workload='SELFTEST (CPU, gloo, no kernels): rank protocol only',
+                               per_gpu_batch=BATCH, global_batch=BATCH * world, parallelism='dp%d' % world))
+        out.update(clock.summary())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def other_config(args, rank, world, dev):
     """cfg1 / cfg2 / cfg4 / cfg5 training throughput (same timing protocol, no roofline block)."""
     import torch.distributed as dist
@@ -106,9 +220,10 @@ def other_config(args, rank, world, dev):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    clock = StepClock(True)
     t0 = time.time(); frames = 0
     for i in range(args.steps):
-        frames += step(args.warmup + i)
+        clock.start(); f = step(args.warmup + i); clock.stop(f); frames += f
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -121,11 +236,13 @@ def other_config(args, rank, world, dev):
         fsum = tt[1:2].clone(); dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
         dt = tmax.item(); frames = fsum.item()
     if rank == 0:
-        print(json.dumps(dict(metric='train frames/sec (node)', value=frames / dt, unit='frames/s', n_gpus=world,
-                              steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
-                              higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
-                              data='synthetic', config=dict(workload=name, per_gpu_batch=BATCH,
-                                                            parallelism='dp%d' % world))))
+        out = dict(metric='train frames/sec (node)', value=frames / dt, unit='frames/s', n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+                   data='synthetic', config=dict(workload=name, per_gpu_batch=BATCH,
+                                                 global_batch=BATCH * world, parallelism='dp%d' % world))
+        out.update(clock.summary())
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
@@ -133,17 +250,25 @@ def other_config(args, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pool', type=int, default=4, help='distinct synthetic batches per rank')
     ap.add_argument('--cfg', type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help='3 = the headline workload (default); 2/4/5 = the other training configs of '
                          'BASELINE.json, reported for DESIGN.md only')
+    ap.add_argument('--selftest-cpu', action='store_true',
+                    help='rehearse the N-rank protocol on the CPU over gloo (no kernels; for tests)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # before any GPU call: spawn the ranks
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world)
     torch.cuda.set_device(local)
     dev = 'cuda:%d' % local
     import torch.distributed as dist
@@ -181,10 +306,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     net.scan_events = []
+    clock = StepClock(True)
     t0 = time.time()
     frames = 0
     for i in range(args.steps):
-        frames += step(args.warmup + i)
+        clock.start(); f = step(args.warmup + i); clock.stop(f); frames += f
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -226,6 +352,7 @@ def main():
                                         'all-reduce+Adam', per_gpu_batch=BATCH, global_batch=BATCH * world,
                                parallelism='dp%d' % world),
                    roofline=roof)
+        out.update(clock.summary())
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(net)
         print(json.dumps(out))

@@ -316,6 +316,26 @@ def test_gloo_world2_bucketed_allreduce(tmp_path):
         assert 'rank %d ok' % r in o
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run spawns two ranks itself (before any GPU
+    call) and relays rank 0's single JSON line; rehearsed on the CPU over gloo (--selftest-cpu)."""
+    import json
+    env = dict((k, v) for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'))
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--selftest-cpu',
+                                   '--steps', '3', '--warmup', '1'], env=env, timeout=300).decode()
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['parallelism'] == 'dp2' and rec['config']['global_batch'] == 32
+    assert rec['steps'] == 3 and rec['warmup'] == 1 and rec['selftest'] is True
+    assert 'ms_per_step_median' in rec and rec['scaling'] == 'weak'
+    # a rank count that disagrees with the launcher's world size is refused, not silently measured
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--selftest-cpu'], env=env2,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b'WORLD_SIZE=1' in r.stderr
+
+
 def test_oracle_updaters_known_answers():
     """Hand-computed steps of libs/lasagne_libs/updates.py formulas (momentum :143-147, nesterov
     :244-249, adamax :662-696, total_norm_constraint :848-855)."""
