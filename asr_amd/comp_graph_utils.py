@@ -6,7 +6,7 @@
   predictor_tbptt :139-156 predict_fn(..., is_first_win) -> [ce_frame_sum, pred_idx]
   ff :321-333              ff_fn(x, mask[, ivec]) -> [posteriors (B,T,C)]
   ff_tbptt :335-351        ff_fn(x, mask, [ivec,] is_first_win) -> [posteriors]
-  eval_net :171-198, eval_net_tbptt :278-319
+  eval_net :171-198, eval_net_tbptt :278-319   (what they return; FER is counted on the device)
 
 The reference builds these from Theano symbols; here the symbolic arguments (`input_data`, ... ) are
 placeholders that are only tested for truthiness (`ivector_data` switches the i-vector argument on),
@@ -78,9 +78,9 @@ def trainer(input_data, input_mask, target_data, target_mask, network, updater, 
         ce, _, _ = _loss(network, args, has_ivec, True, delay=delay)
         network.backward()
         red.finish()
+        red.agree_on_status()        # BEFORE the update: an aborted scan must not reach the parameters
         gn = update.apply(network, want_sqrt=True)
         out = torch.cat([ce, gn]).cpu().numpy()
-        network.check_status()
         return [np.float32(out[0]), np.float32(out[1])]
 
     return training_fn, trainer_params
@@ -97,9 +97,9 @@ def trainer_tbptt(input_data, input_mask, target_data, target_mask, network, upd
         ce, _, _ = _loss(network, args, has_ivec, True, delay=delay, context=context, tbptt=True)
         network.backward()
         red.finish()
+        red.agree_on_status()
         gn = update.apply(network, want_sqrt=False)          # un-rooted sum (:111)
         out = torch.cat([ce, gn]).cpu().numpy()
-        network.check_status()
         return [np.float32(out[0]), np.float32(out[1])]
 
     return training_fn, trainer_params
@@ -113,6 +113,13 @@ def predictor(input_data, input_mask, target_data, target_mask, network, delay=0
         network.check_status()
         return [np.float32(ce.item()), pred.cpu().numpy().astype(np.int64)]
 
+    def stats(*args):
+        ce, hits, _ = _loss(network, args, has_ivec, False, delay=delay)
+        out = torch.cat([ce, hits]).cpu().numpy()
+        network.check_status()
+        return np.float32(out[0]), float(out[1])
+
+    fn.stats = stats
     return fn
 
 
@@ -125,6 +132,13 @@ def predictor_tbptt(input_data, input_mask, target_data, target_mask, network, t
         network.check_status()
         return [np.float32(ce.item()), pred.cpu().numpy().astype(np.int64)]
 
+    def stats(*args):
+        ce, hits, _ = _loss(network, args, has_ivec, False, delay=delay, context=context, tbptt=True)
+        out = torch.cat([ce, hits]).cpu().numpy()
+        network.check_status()
+        return np.float32(out[0]), float(out[1])
+
+    fn.stats = stats
     return fn
 
 
@@ -174,54 +188,68 @@ def ff_tbptt(input_data, input_mask, network, is_first_win, delay, num_tbptt_ste
     return fn
 
 
+class _Tally(object):
+    """Running sums of one evaluation pass: CE frame sum, correct frames, scored frames."""
+    def __init__(self):
+        self.ce = 0.0
+        self.hits = 0.0
+        self.frames = 0.0
+
+    def result(self):
+        return self.ce / self.frames, 1.0 - self.hits / self.frames
+
+
+def _score(predict_fn, inputs, y, ymask):
+    """-> (ce_frame_sum, correct frames or None, pred_idx or None).  The callables built by this module
+    count the correct frames on the device (`row_ok` of the softmax-CE kernel summed by asr_reduce_sum)
+    and hand back two scalars; the (B,T) argmax is only copied to the host for a foreign predict_fn."""
+    fast = getattr(predict_fn, 'stats', None)
+    if fast is not None:
+        ce, hits = fast(*inputs)
+        return ce, hits, None
+    ce, pred = predict_fn(*inputs)
+    return ce, None, pred
+
+
 def eval_net(predict_fn, data_stream, use_ivectors=False, delay=0):
-    total_ce_sum = 0.
-    total_accuracy_sum = 0
-    total_frame_count = 0
-    for batch_cnt, data in enumerate(data_stream.get_epoch_iterator(), start=1):
-        input_data, input_mask, ivector_data, ivector_mask, target_data, target_mask = data
-        if use_ivectors:
-            predict_output = predict_fn(input_data, input_mask, ivector_data, target_data, target_mask)
-        else:
-            predict_output = predict_fn(input_data, input_mask, target_data, target_mask)
-        ce_frame_sum, pred_idx = predict_output
-        target_data, target_mask = target_data[:, delay:], target_mask[:, delay:]
-        match_data = (target_data == pred_idx) * target_mask
-        total_accuracy_sum += match_data.sum()
-        total_ce_sum += ce_frame_sum
-        total_frame_count += target_mask.sum()
-    avg_ce = total_ce_sum / total_frame_count
-    avg_fer = 1.0 - (total_accuracy_sum / total_frame_count)
-    return avg_ce, avg_fer
+    """-> (CE per frame, frame error rate) over one pass of the stream; the first `delay` target frames
+    of every utterance are not scored (libs/comp_graph_utils.py:18-19,188)."""
+    tally = _Tally()
+    for x, xm, iv, _, y, ym in data_stream.get_epoch_iterator():
+        inputs = (x, xm, iv, y, ym) if use_ivectors else (x, xm, y, ym)
+        ce, hits, pred = _score(predict_fn, inputs, y, ym)
+        scored = ym[:, delay:]
+        if hits is None:
+            hits = ((y[:, delay:] == pred) * scored).sum()
+        tally.ce += ce
+        tally.hits += hits
+        tally.frames += scored.sum()
+    return tally.result()
 
 
 def eval_net_tbptt(predict_fn, data_stream, tbptt_layers, num_tbptt_steps, batch_size, right_context,
                    use_ivectors=False, delay=0):
-    total_accuracy_sum = 0
-    total_ce_sum = 0.
-    total_frame_count = 0
-    for b_idx, batch in enumerate(data_stream.get_epoch_iterator(), start=1):
-        i_data, _, _, _, t_data, t_mask = batch
-        n_batch = i_data.shape[0]
-        for l in tbptt_layers:
-            l.reset(n_batch)
-        pred_idx_list = []
-        for win_idx, win in enumerate(gen_win(batch, num_tbptt_steps, right_context), start=1):
-            input_data, input_mask, ivector_data, ivector_mask, target_data, target_mask = win
-            is_first_win = 1 if win_idx == 1 else 0
-            if use_ivectors:
-                predict_output = predict_fn(input_data, input_mask, ivector_data, target_data, target_mask,
-                                            is_first_win)
+    """The windowed form: state reset per batch, one predict call per window (first one flagged), the
+    per-window predictions laid end to end against the whole utterance's targets."""
+    tally = _Tally()
+    for batch in data_stream.get_epoch_iterator():
+        y_all, ym_all = batch[4], batch[5]
+        for layer in tbptt_layers:
+            layer.reset(batch[0].shape[0])
+        hits = 0.0
+        preds = []
+        for k, (x, xm, iv, _, y, ym) in enumerate(gen_win(batch, num_tbptt_steps, right_context)):
+            first = 1 if k == 0 else 0
+            inputs = (x, xm, iv, y, ym, first) if use_ivectors else (x, xm, y, ym, first)
+            ce, h, pred = _score(predict_fn, inputs, y, ym)
+            tally.ce += ce
+            if h is None:
+                preds.append(pred)
             else:
-                predict_output = predict_fn(input_data, input_mask, target_data, target_mask, is_first_win)
-            ce_frame_sum, pred_idx = predict_output
-            total_ce_sum += ce_frame_sum
-            pred_idx_list.append(pred_idx)
-        target_data, target_mask = t_data[:, delay:], t_mask[:, delay:]
-        pred_idx = np.concatenate(pred_idx_list, axis=1)
-        match_data = (target_data == pred_idx) * target_mask
-        total_accuracy_sum += match_data.sum()
-        total_frame_count += target_mask.sum()
-    avg_ce = total_ce_sum / total_frame_count
-    avg_fer = 1.0 - (total_accuracy_sum / total_frame_count)
-    return avg_ce, avg_fer
+                hits += h
+        scored = ym_all[:, delay:]
+        if preds:
+            hits = ((y_all[:, delay:] == np.concatenate(preds, axis=1)) * scored).sum()
+        tally.hits += hits
+        tally.frames += scored.sum()
+    return tally.result()

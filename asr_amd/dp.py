@@ -39,6 +39,24 @@ class GradAllReduce(object):
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
 
+    def agree_on_status(self):
+        """Called between the gradient exchange and the optimiser step: one host sync, then every rank
+        learns whether ANY rank's persistent scan gave up (ASR_ERR_TIMEOUT), and all of them raise
+        together with parameters, optimiser state and carried TBPTT state untouched by the bad step."""
+        err = None
+        try:
+            self.net.check_status()
+        except Exception as e:                    # noqa: BLE001 -- re-raised below on every rank
+            err = e
+        if self.world > 1:
+            flag = torch.tensor([1.0 if err is not None else 0.0], device=self.net.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if err is None and flag.item() != 0.0:
+                from ._lib import AsrError
+                err = AsrError('a persistent scan failed on another rank; step skipped on every rank')
+        if err is not None:
+            raise err
+
     def reduce_scalars(self, t):
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

@@ -61,11 +61,11 @@ def build_trainer(input_data, input_mask, target_data, target_mask, network_para
                                  ym, cond=None, train=True)
         network.backward()
         red.finish()
+        red.agree_on_status()
         if wd_coef:
             network.add_weight_decay(wd_coef, lasagne_regularizable)
         gn = update.apply(network, want_sqrt=True)
         out = torch.cat([ce, ok, gn, ym.sum().reshape(1)]).cpu().numpy()
-        network.check_status()
         nfr = max(float(out[3]), 1.0)
         # train_feat_loss (:120-127) is reported even at feat_reg = 0: -mean(var(sample_feat, axis=0))
         # averaged over the conditioning layers; a host-side read-out of the pooled features
@@ -105,9 +105,9 @@ def build_prj_hyper_trainer(input_data, input_mask, target_data, target_mask, ne
         inter, intra = pair.aux_costs(float(inter_weight), float(intra_weight))
         network.backward()
         red.finish()
+        red.agree_on_status()
         gn = update.apply(network, want_sqrt=True)
         out = torch.cat([ce, ok, gn, ym.sum().reshape(1)]).cpu().numpy()
-        network.check_status()
         nfr = max(float(out[3]), 1.0)
         return [np.float32(out[0] / nfr), np.float32(out[1] / nfr), np.float32(out[2]), np.float32(inter),
                 np.float32(intra)]

@@ -1,22 +1,28 @@
-"""Host-side utilities with the reference's names and behaviour:
-  save_network / load_or_init_model / find_reload_model   libs/utils.py:80-85, :154-175
-  set_model_param_value / get_model_param_values          libs/lasagne_libs/utils.py:2-17
-  gen_win / gen_win_test (TBPTT windowing)                libs/utils.py:178-205
-  StopWatch, show_status, EvalRecord history helpers      libs/utils.py:29-50, :87-107
+"""Host-side bookkeeping around the engine.  The contract taken from the reference is the DATA and the
+call surface, not the code:
 
-Pickle layout: [ [ndarray, ...], updater_vals, epoch_cnt ].  The reference's
-get_update_params_values has no `return` (libs/param_utils.py:20-23), so element [1] of every
-reference pickle is None; we write None as well unless an optimiser state dict is passed explicitly,
-and accept either on load.  Python-2 pickles are read with encoding='latin1'; ours are written with
-protocol 2 so the reference's Python 2 can read them back.
+  * the model file (libs/utils.py:80-85, :154-166): a pickle of [ [ndarray, ...], updater_vals, epoch ]
+    with the arrays in get_all_params(trainable=True) order; `updater_vals` is None in every file the
+    reference writes (its get_update_params_values has no `return`, libs/param_utils.py:20-23), and we
+    write None as well.  Written with protocol 2 so Python 2 can read it back; read with a RESTRICTED
+    unpickler (numpy arrays / scalars and plain containers only) -- a model file named on a command
+    line must not be able to run code;
+  * the evaluation history file (libs/utils.py:87-99): a pickle of a list of 5-tuples
+    (train_ce_frame, valid_ce_frame, valid_fer, test_ce_frame, test_fer);
+  * the TBPTT windows (libs/utils.py:178-205): frames [i, i + win + right_context) for i = 0, win, ...;
+  * the status lines the training scripts print (libs/utils.py:102-107, :46-50).
+
+The function names the reference's scripts import (save_network, load_or_init_model, find_reload_model,
+gen_win, gen_win_test, StopWatch, show_status, best_fer, save_eval_history, EvalRecord) are thin fronts
+over `Checkpoint`, `EvalHistory` and `windows()` below.
 """
 from __future__ import print_function
 
+import io
 import os
 import pickle
 import time
-from collections import namedtuple
-from operator import attrgetter
+from collections import OrderedDict, namedtuple
 
 import numpy as np
 
@@ -24,132 +30,223 @@ EvalRecord = namedtuple('EvalRecord', ['train_ce_frame', 'valid_ce_frame', 'vali
                                        'test_fer'])   # scripts/exp_deep_lstm2.py:100-101
 
 
-def _param_list(network_params):
-    """Accepts the Network itself or the list returned by Network.get_all_params()."""
-    if hasattr(network_params, 'get_all_params'):
-        return network_params.get_all_params(trainable=True)
-    return list(network_params)
-
-
-def get_model_param_values(params_list):
-    return [p.get_value() for p in _param_list(params_list)]
-
-
-def set_model_param_value(params_var_list, params_val_list):
-    params_var_list = _param_list(params_var_list)
-    if len(params_var_list) != len(params_val_list):
-        raise ValueError("mismatch: got %d values to set %d parameters" %
-                         (len(params_val_list), len(params_var_list)))
-    shapes = [p.get_value().shape for p in params_var_list]
-    for shp, v in zip(shapes, params_val_list):
-        if tuple(shp) != tuple(np.shape(v)):
-            raise ValueError("mismatch: parameter has shape %r but value to "
-                             "set has shape %r" % (tuple(shp), tuple(np.shape(v))))
-    for p, v in zip(params_var_list, params_val_list):
-        p.set_value(v)
-
-
-def get_update_params_values(params_var_dict):
-    """The reference returns None here (missing `return`); keep that so pickles are byte-compatible
-    in structure.  Use `trainer_params` objects' own state_dict() for a full optimiser resume."""
+# ------------------------------------------------------------------------------------------------
+# restricted unpickling
+def _numpy_global(module, name):
+    mod = module.replace('numpy.core', 'numpy._core')      # numpy < 2 wrote numpy.core.*
+    if mod == 'numpy._core.multiarray' and name in ('_reconstruct', 'scalar'):
+        import numpy._core.multiarray as m
+        return getattr(m, name)
+    if mod == 'numpy._core.numeric' and name == '_frombuffer':
+        import numpy._core.numeric as m
+        return m._frombuffer
+    if mod == 'numpy' and name in ('ndarray', 'dtype'):
+        return getattr(np, name)
     return None
 
 
+class _DataUnpickler(pickle.Unpickler):
+    """Resolves only what an array list needs: numpy's array / scalar / dtype reconstructors,
+    OrderedDict (an updater-state dict) and this module's EvalRecord.  Anything else -- os.system,
+    builtins.eval, a class with __reduce__ -- raises UnpicklingError before it can be called."""
+    def find_class(self, module, name):
+        g = _numpy_global(module, name)
+        if g is not None:
+            return g
+        if (module, name) == ('collections', 'OrderedDict'):
+            return OrderedDict
+        if name == 'EvalRecord':
+            return EvalRecord
+        if (module, name) in (('_codecs', 'encode'), ('codecs', 'encode')):
+            import codecs                       # protocol-2 bytes objects written by Python 3
+            return codecs.encode
+        raise pickle.UnpicklingError('asr_amd refuses to unpickle %s.%s: model and history files hold '
+                                     'numpy arrays and plain containers only' % (module, name))
+
+
+def _read_data_pickle(path):
+    with open(path, 'rb') as f:
+        raw = f.read()
+    try:
+        return _DataUnpickler(io.BytesIO(raw)).load()
+    except UnicodeDecodeError:                  # a Python 2 str holding array bytes
+        return _DataUnpickler(io.BytesIO(raw), encoding='latin1').load()
+
+
+# ------------------------------------------------------------------------------------------------
+# parameters <-> value lists
+def _handles(network_or_params):
+    """The Network itself or the list its get_all_params() returns (objects with get_value/set_value)."""
+    if hasattr(network_or_params, 'get_all_params'):
+        return network_or_params.get_all_params(trainable=True)
+    return list(network_or_params)
+
+
+def get_model_param_values(params_list):
+    return [h.get_value() for h in _handles(params_list)]
+
+
+def set_model_param_value(params_var_list, params_val_list):
+    """All-or-nothing: every count / shape is checked before the first value is written
+    (messages of libs/lasagne_libs/utils.py:2-14)."""
+    handles = _handles(params_var_list)
+    values = list(params_val_list)
+    if len(handles) != len(values):
+        raise ValueError("mismatch: got %d values to set %d parameters" % (len(values), len(handles)))
+    for h, v in zip(handles, values):
+        have, want = tuple(np.shape(v)), tuple(h.get_value().shape)
+        if have != want:
+            raise ValueError("mismatch: parameter has shape %r but value to set has shape %r" % (want, have))
+    for h, v in zip(handles, values):
+        h.set_value(v)
+
+
+def get_update_params_values(params_var_dict):
+    """None, as in every file the reference writes (see the module docstring)."""
+    return None
+
+
+class Checkpoint(object):
+    """One model file."""
+    def __init__(self, values, updater_values=None, epoch=0):
+        self.values = list(values)
+        self.updater_values = updater_values
+        self.epoch = int(epoch)
+
+    @classmethod
+    def of(cls, network_or_params, epoch, updater_values=None):
+        return cls(get_model_param_values(network_or_params), updater_values, epoch)
+
+    @classmethod
+    def read(cls, path):
+        obj = _read_data_pickle(path)
+        if not isinstance(obj, (list, tuple)) or len(obj) != 3 or not isinstance(obj[0], (list, tuple)):
+            raise ValueError('%s is not a [params, updater_vals, epoch] model pickle' % path)
+        return cls([np.asarray(a) for a in obj[0]], obj[1], obj[2])
+
+    def write(self, path):
+        tmp = path + '.tmp%d' % os.getpid()         # a killed run never leaves half a model behind
+        with open(tmp, 'wb') as f:
+            pickle.dump([self.values, self.updater_values, self.epoch], f, protocol=2)
+        os.replace(tmp, path)
+
+    def as_list(self):
+        return [self.values, self.updater_values, self.epoch]
+
+
 def save_network(network_params, trainer_params, epoch_cnt, save_path):
-    with open(save_path, 'wb') as f:
-        cur_network_params_val = get_model_param_values(network_params)
-        cur_trainer_params_val = get_update_params_values(trainer_params)
-        pickle.dump([cur_network_params_val, cur_trainer_params_val, epoch_cnt], f, protocol=2)
+    Checkpoint.of(network_params, epoch_cnt, get_update_params_values(trainer_params)).write(save_path)
 
 
 def load_network_pickle(path):
-    with open(path, 'rb') as f:
-        try:
-            obj = pickle.load(f)
-        except UnicodeDecodeError:
-            f.seek(0)
-            obj = pickle.load(f, encoding='latin1')
-    if not isinstance(obj, (list, tuple)) or len(obj) != 3:
-        raise ValueError('%s is not a [params, updater_vals, epoch] model pickle' % path)
-    return obj
+    return Checkpoint.read(path).as_list()
 
 
 def load_or_init_model(network_params, args):
-    pretrain_update_params_val = None
-    pretrain_total_epoch_cnt = 0
-    if getattr(args, 'reload_model', None):
-        print('Loading the model: {}'.format(args.reload_model))
-        pretrain_network_params_val, pretrain_update_params_val, pretrain_total_epoch_cnt = \
-            load_network_pickle(args.reload_model)
-        set_model_param_value(network_params, pretrain_network_params_val)
-    return pretrain_update_params_val, pretrain_total_epoch_cnt
+    """-> (updater values or None, number of epochs already trained)."""
+    path = getattr(args, 'reload_model', None)
+    if not path:
+        return None, 0
+    print('Loading the model: {}'.format(path))
+    ck = Checkpoint.read(path)
+    set_model_param_value(network_params, ck.values)
+    return ck.updater_values, ck.epoch
 
 
 def find_reload_model(args):
-    if not args.reload_model and not args.no_reload:
-        reload_path = args.save_path + '_last_model.pkl'
-        if os.path.exists(reload_path):
-            print('Previously trained model detected: {}'.format(reload_path))
-            print('Training continues')
-            args.reload_model = reload_path
+    """Resume from <save_path>_last_model.pkl unless a model was named or --no-reload given."""
+    if args.reload_model or args.no_reload:
+        return
+    candidate = args.save_path + '_last_model.pkl'
+    if os.path.exists(candidate):
+        print('Previously trained model detected: {}'.format(candidate))
+        print('Training continues')
+        args.reload_model = candidate
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation history
+class EvalHistory(list):
+    """List of EvalRecord; starts with the reference's sentinel row (scripts/exp_deep_lstm2.py:113)."""
+    SENTINEL = EvalRecord(10.1, 10.0, 1.0, 10.0, 1.0)
+
+    def __init__(self, records=None):
+        list.__init__(self, [self.SENTINEL] if records is None else records)
+
+    def best_valid_fer(self):
+        return min(r.valid_fer for r in self)
+
+    def add(self, train_ce, valid, test):
+        """valid / test: (ce_frame, fer).  Returns True when this epoch is the best so far."""
+        improved = valid[1] < self.best_valid_fer()
+        self.append(EvalRecord(train_ce, valid[0], valid[1], test[0], test[1]))
+        return improved
+
+    def save(self, path):
+        with open(path, 'wb') as f:
+            pickle.dump([tuple(r) for r in self], f, protocol=2)
+
+    @classmethod
+    def load(cls, path):
+        return cls([EvalRecord(*r) for r in _read_data_pickle(path)])
 
 
 def save_eval_history(eval_history, save_path):
-    with open(save_path, 'wb') as f:
-        pickle.dump([tuple(r) for r in eval_history], f, protocol=2)
+    EvalHistory(list(eval_history)).save(save_path)
 
 
 def best_fer(eval_history):
-    acopy = list(eval_history)
-    acopy.sort(key=attrgetter('valid_fer'))
-    return acopy[0].valid_fer
+    return min(r.valid_fer for r in eval_history)
 
 
+# ------------------------------------------------------------------------------------------------
+# status lines
 def show_status(save_path, ce_frame, network_grads_norm, batch_idx, batch_size, epoch_idx):
-    model = save_path.split('/')[-1]
     print('--')
-    print('Model Name: {} (Epoch {})'.format(model, epoch_idx))
+    print('Model Name: {} (Epoch {})'.format(os.path.basename(save_path), epoch_idx))
     print('Train CE {} (batch {}, {} examples so far): '.format(ce_frame, batch_idx, batch_idx * batch_size))
     print('Gradient Norm: {}'.format(network_grads_norm))
 
 
 class StopWatch(object):
-    """libs/utils.py:29-50."""
     def __init__(self):
-        self.start_time = time.time()
+        self.reset()
 
     def reset(self):
-        self.start_time = time.time()
+        self.t0 = time.time()
 
     def elapsed(self):
-        return time.time() - self.start_time
+        return time.time() - self.t0
 
     def print_elapsed(self):
-        time_diff = time.time() - self.start_time
-        print('Took {:.1f}s ({:.1f}m; {:.1f}h)'.format(time_diff, time_diff / 60, time_diff / 3600))
+        s = self.elapsed()
+        print('Took {:.1f}s ({:.1f}m; {:.1f}h)'.format(s, s / 60, s / 3600))
+
+
+# ------------------------------------------------------------------------------------------------
+# TBPTT windows
+def windows(n_seq, win_size, right_context=0):
+    """Slices [i, i + win_size + right_context) for i = 0, win_size, ...: the look-ahead frames are
+    processed again by the next window (numpy clips the last slice)."""
+    return [slice(i, i + win_size + right_context) for i in range(0, n_seq, win_size)]
+
+
+def _cut(batch, n_items):
+    arrays = tuple(batch)
+    if len(arrays) != n_items:
+        raise ValueError('expected a %d-tuple batch, got %d items' % (n_items, len(arrays)))
+    return arrays, arrays[0].shape[1]
 
 
 def gen_win(batch, win_size, right_context=0):
-    """Windows of `win_size` frames plus `right_context` look-ahead frames that the next window
-    re-processes (libs/utils.py:178-191)."""
-    input_data, input_mask, ivector_data, ivector_mask, target_data, target_mask = batch
-    n_batch, n_seq, n_feat = input_data.shape
-    for i in range(0, n_seq, win_size):
-        from_idx = i
-        to_idx = i + win_size + right_context
-        yield (input_data[:, from_idx:to_idx, :], input_mask[:, from_idx:to_idx],
-               ivector_data[:, from_idx:to_idx, :] if ivector_data is not None else None,
-               ivector_mask[:, from_idx:to_idx] if ivector_mask is not None else None,
-               target_data[:, from_idx:to_idx], target_mask[:, from_idx:to_idx])
+    """batch = (x, x_mask, ivec, ivec_mask, y, y_mask); absent i-vector entries stay None."""
+    arrays, n_seq = _cut(batch, 6)
+    for s in windows(n_seq, win_size, right_context):
+        yield tuple(None if a is None else a[:, s] for a in arrays)
 
 
 def gen_win_test(batch, win_size, right_context=0):
-    """libs/utils.py:193-205."""
-    input_data, input_mask, ivector_data, ivector_mask = batch
-    n_batch, n_seq, n_feat = input_data.shape
-    for i in range(0, n_seq, win_size):
-        from_idx = i
-        to_idx = i + win_size + right_context
-        yield (input_data[:, from_idx:to_idx, :], input_mask[:, from_idx:to_idx],
-               ivector_data[:, from_idx:to_idx, :] if ivector_data is not None else None,
-               ivector_mask[:, from_idx:to_idx] if ivector_mask is not None else None)
+    """The 4-tuple form of the forward scripts: (x, x_mask, ivec, ivec_mask)."""
+    arrays, n_seq = _cut(batch, 4)
+    for s in windows(n_seq, win_size, right_context):
+        yield tuple(None if a is None else a[:, s] for a in arrays)

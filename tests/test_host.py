@@ -173,6 +173,45 @@ def test_python2_style_pickle_loads(tmp_path):
     assert epoch == 3 and np.array_equal(vals[0], arr)
 
 
+def test_model_pickle_refuses_code(tmp_path):
+    """A model / history file is data: anything but numpy arrays and plain containers is refused
+    before it can run (the loaders sit behind `python -m asr_amd.forward MODEL` and --reload-model)."""
+    from asr_amd import utils
+
+    class Boom(object):
+        def __reduce__(self):
+            return (os.system, ('touch %s' % (tmp_path / 'pwned'),))
+
+    p = str(tmp_path / 'evil.pkl')
+    for payload in ([[np.zeros(2, np.float32)], Boom(), 1], Boom()):
+        with open(p, 'wb') as f:
+            pickle.dump(payload, f, protocol=2)
+        with pytest.raises(pickle.UnpicklingError, match='refuses'):
+            utils.load_network_pickle(p)
+        with pytest.raises(pickle.UnpicklingError):
+            utils.EvalHistory.load(p)
+    assert not (tmp_path / 'pwned').exists()
+    # what the package itself writes stays readable: float32/float64/int arrays, numpy scalars, epoch
+    vals = [np.arange(6, dtype=np.float32).reshape(2, 3), np.ones(3, np.float64), np.array(5, np.int32)]
+    for proto in (2, pickle.HIGHEST_PROTOCOL):
+        with open(p, 'wb') as f:
+            pickle.dump([vals, None, np.int64(4)], f, protocol=proto)
+        got, upd, epoch = utils.load_network_pickle(p)
+        assert upd is None and int(epoch) == 4 and all(np.array_equal(a, b) for a, b in zip(got, vals))
+    h = utils.EvalHistory()
+    assert h.add(1.0, (2.0, 0.5), (2.1, 0.6)) and not h.add(1.0, (2.0, 0.7), (2.1, 0.6))
+    h.save(p)
+    back = utils.EvalHistory.load(p)
+    assert [tuple(r) for r in back] == [tuple(r) for r in h] and back.best_valid_fer() == 0.5
+
+
+def test_lr_schedule_of_the_hypernet_scripts():
+    from asr_amd.train import lr_schedule
+    # scripts/hypernets/exp_prj_ln_lstm_fix.py:316 with Python-2 integer division
+    assert [round(lr_schedule(1.0, e), 6) for e in (1, 2, 3, 4, 5, 6)] == [
+        1.0, 1.0, 1.0, round(1 / 1.04, 6), round(1 / 1.04, 6), round(1 / 1.04 ** 2, 6)]
+
+
 def test_gen_win_matches_reference_windowing():
     from asr_amd import utils
     B, T, D = 2, 23, 3
