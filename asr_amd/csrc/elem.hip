@@ -245,7 +245,8 @@ __global__ __launch_bounds__(64) void colreduce1_kernel(const float* __restrict_
     const int c = blockIdx.x * 64 + threadIdx.x;
     const int s = blockIdx.y, g = blockIdx.z;
     if (c >= n) return;
-    const int per = (rows / gmod + CR_SPLIT - 1) / CR_SPLIT;     // group-rows per split
+    const int per = ((rows + gmod - 1) / gmod + CR_SPLIT - 1) / CR_SPLIT;   // group-rows per split, sized for the
+                                                                            // fullest group (rows % gmod != 0)
     const int q0 = s * per;
     int q1 = q0 + per;
     const int nq = (rows - g + gmod - 1) / gmod;                 // rows in this group

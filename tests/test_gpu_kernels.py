@@ -60,6 +60,20 @@ def test_ln_rows_and_colreduce():
     assert relerr(out.cpu().numpy(), ref) < 1e-5
 
 
+def test_colreduce_ragged_groups():
+    """rows % gmod != 0 with floor(rows/gmod) a multiple of the 32 row splits: the fullest groups hold
+    one row more than the split size was once derived from (their last row was dropped)."""
+    from asr_amd import ops
+    rng = np.random.default_rng(5)
+    for rows, gmod, n in ((32 * 3 + 1, 3, 70), (64 * 4 + 3, 4, 9), (33 * 5 + 1, 5, 130)):
+        x = rng.standard_normal((rows, n)).astype(np.float32)
+        out = torch.empty(gmod, n, device='cuda')
+        ops.colreduce(torch.from_numpy(x).cuda(), out, rows, n, gmod=gmod)
+        ref = np.zeros((gmod, n))
+        np.add.at(ref, np.arange(rows) % gmod, x.astype(np.float64))
+        assert relerr(out.cpu().numpy(), ref) < 1e-5, (rows, gmod)
+
+
 def test_ln_rows_per_gate():
     """groups=4 (gate_ln / sample_gate_ln): the kernel works on gate-interleaved columns (col = unit*4 +
     gate), the oracle on the reference's gate-major blocks."""

@@ -1,0 +1,49 @@
+"""The allocation-free entry point asr_colreduce_static (include/asr_amd.h) against asr_colreduce, through
+the C-ABI: bit-exact on two calls in a row, the second with a smaller input, plus the size limit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from asr_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(rows, n, gmod, with_y, seed):
+    L = _lib.lib()
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.randn(rows, n, generator=g).cuda()
+    y = torch.randn(rows, n, generator=g).cuda() if with_y else None
+    out_a = torch.full((gmod, n), 7.0, device='cuda'); out_b = out_a.clone()
+    ws = torch.empty(L.asr_colreduce_ws_bytes(n, gmod) // 4, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    yp = y.data_ptr() if with_y else None
+    rc = L.asr_colreduce(x.data_ptr(), n, yp, n, rows, n, gmod, out_a.data_ptr(), 1, ws.data_ptr(),
+                         ws.numel() * 4, st)
+    assert rc == 0
+    rc = L.asr_colreduce_static(x.data_ptr(), n, yp, n, rows, n, gmod, out_b.data_ptr(), 1, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = 7.0 + (x * (y if with_y else 1.0)).double().view(-1, gmod, n).sum(0) if rows % gmod == 0 else None
+    return out_a.cpu().numpy(), out_b.cpu().numpy(), None if ref is None else ref.cpu().numpy()
+
+
+def test_static_scratch_colreduce_matches_workspace_form_twice():
+    a, b, ref = _both(16 * 300, 2048, 16, True, 1)           # fills the built-in buffer exactly (gmod*n = 32768)
+    assert np.array_equal(a, b)
+    assert np.abs(a - ref).max() < 2e-3
+    a, b, ref = _both(33 * 4 + 1, 100, 4, False, 2)          # smaller, ragged groups, stale partials behind it
+    assert np.array_equal(a, b)
+    a, b, ref = _both(8 * 50, 512, 8, True, 3)
+    assert np.array_equal(a, b) and np.abs(a - ref).max() < 1e-3
+
+
+def test_static_scratch_colreduce_rejects_oversize():
+    L = _lib.lib()
+    x = torch.zeros(4, 32772, device='cuda'); out = torch.zeros(32772, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.asr_colreduce_static(x.data_ptr(), 32772, None, 0, 4, 32772, 1, out.data_ptr(), 0, st) == -5
+    assert L.asr_colreduce_static(x.data_ptr(), 2049, None, 0, 4, 2049, 16, out.data_ptr(), 0, st) == -5
+    assert L.asr_colreduce_static(None, 4, None, 0, 4, 4, 1, out.data_ptr(), 0, st) == -1
