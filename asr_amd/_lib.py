@@ -6,7 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ASR_AMD_LIB') or os.path.join(_HERE, 'libasr_amd.so')
 
-ERR = {0: 'ASR_OK', -1: 'ASR_ERR_ARG', -2: 'ASR_ERR_LAUNCH', -3: 'ASR_ERR_WS', -4: 'ASR_ERR_TIMEOUT'}
+ERR = {0: 'ASR_OK', -1: 'ASR_ERR_ARG', -2: 'ASR_ERR_LAUNCH', -3: 'ASR_ERR_WS', -4: 'ASR_ERR_TIMEOUT',
+       -5: 'ASR_ERR_LIMIT'}
 
 fp = C.c_void_p          # device pointers travel as integers
 i32 = C.c_int
@@ -62,6 +63,7 @@ _SIGS = {
     'asr_ln_rows_bwd': (i32, [fp, i32, i32, fp, fp, fp, i32, fp, i32, fp]),
     'asr_colreduce_ws_bytes': (sz, [i32, i32]),
     'asr_colreduce': (i32, [fp, i32, fp, i32, i32, i32, i32, fp, i32, fp, sz, fp]),
+    'asr_colreduce_static': (i32, [fp, i32, fp, i32, i32, i32, i32, fp, i32, fp]),
     'asr_bias_act': (i32, [fp, fp, i32, i32, i32, fp]),
     'asr_act_bwd': (i32, [fp, fp, i32, i32, i32, fp]),
     'asr_rowscale': (i32, [fp, i32, fp, i32, i32, fp, i32, i32, i32, fp]),

@@ -2,6 +2,7 @@
 // out of the recurrence), deterministic column reductions for the vector-parameter gradients,
 // bias/activation for the small LHUC / conditioning MLPs, masked mean pooling.
 #include "common.h"
+#include <mutex>
 
 // ------------------------------------------------------------------ permute (A,B,D) -> (B,A,D)
 __global__ void swap01_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int B,
@@ -303,6 +304,48 @@ extern "C" int asr_colreduce(const float* x, int ldx, const float* y, int ldy, i
     hipLaunchKernelGGL(colreduce1_kernel, g1, dim3(64), 0, stream, x, ldx, y, ldy, rows, n, gmod, ws);
     ASR_CHECK_LAUNCH();
     size_t tot = (size_t)gmod * n;
+    hipLaunchKernelGGL(colreduce2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, ws,
+                       n, gmod, out, accumulate);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// The same reduction for callers that cannot allocate or hand over a workspace (code under HIP graph
+// capture, tight serving loops): the stage-1 partials live in a file-scope device array.  Its name is
+// only a host-side handle; the device address is looked up once per device (hipGetSymbolAddress) and
+// that pointer is what the kernels get.  Every call on a GPU shares that GPU's array: calls that
+// overlap on one GPU (two streams) race.  Nothing in it has to start at zero (stage 1 writes every
+// partial stage 2 reads).
+#define CR_STATIC_MAX 32768                       // gmod * n of one call
+static __device__ __align__(256) float cr_static_scratch[(size_t)CR_SPLIT * CR_STATIC_MAX];   // 4 MiB per GPU
+#define CR_MAX_DEVICES 64
+static float* cr_static_ptr[CR_MAX_DEVICES];
+static std::mutex cr_static_mu;
+
+static int cr_static_lookup(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CR_MAX_DEVICES) return ASR_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lk(cr_static_mu);
+    if (!cr_static_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(cr_static_scratch)) != hipSuccess || !p) return ASR_ERR_LAUNCH;
+        cr_static_ptr[dev] = (float*)p;
+    }
+    *out = cr_static_ptr[dev];
+    return ASR_OK;
+}
+
+extern "C" int asr_colreduce_static(const float* x, int ldx, const float* y, int ldy, int rows, int n, int gmod,
+                                    float* out, int accumulate, hipStream_t stream) {
+    if (rows < 0 || n <= 0 || gmod <= 0 || !x || !out) return ASR_ERR_ARG;
+    if ((size_t)gmod * (size_t)n > CR_STATIC_MAX) return ASR_ERR_LIMIT;
+    float* ws = nullptr;
+    const int rc = cr_static_lookup(&ws);
+    if (rc != ASR_OK) return rc;
+    dim3 g1((n + 63) / 64, CR_SPLIT, gmod);
+    hipLaunchKernelGGL(colreduce1_kernel, g1, dim3(64), 0, stream, x, ldx, y, ldy, rows, n, gmod, ws);
+    ASR_CHECK_LAUNCH();
+    const size_t tot = (size_t)gmod * n;
     hipLaunchKernelGGL(colreduce2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, ws,
                        n, gmod, out, accumulate);
     ASR_CHECK_LAUNCH();

@@ -27,6 +27,7 @@ typedef struct ihipStream_t* asr_stream_t; /* hipStream_t */
 #define ASR_ERR_LAUNCH (-2)
 #define ASR_ERR_WS (-3)
 #define ASR_ERR_TIMEOUT (-4)
+#define ASR_ERR_LIMIT (-5)   /* larger than a fixed built-in buffer (asr_colreduce_static) */
 
 /* K1.  C = alpha*op(A)*op(B) + beta*C (+bias[N] per row); exact-fp32 MFMA.  Replaces every T.dot on
  * the path: input projection libs/lhuclstm_layers.py:189, libs/lasagne_libs/recurrent_layers.py:701,
@@ -60,6 +61,14 @@ int asr_ln_rows_bwd(const float* dy, int rows, int n, const float* xhat, const f
 size_t asr_colreduce_ws_bytes(int n, int gmod);
 int asr_colreduce(const float* x, int ldx, const float* y, int ldy, int rows, int n, int gmod,
                   float* out, int accumulate, float* ws, size_t ws_bytes, asr_stream_t stream);
+
+/* asr_colreduce for callers that cannot allocate or carry a workspace (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The stage-1
+ * partials live in a 4 MiB device array built into the library (one copy per GPU, held until the process
+ * ends), so gmod * n <= 32768 or ASR_ERR_LIMIT.  The call allocates nothing; `stream` must belong to the
+ * current device.  All calls on one GPU share that array: calls that overlap on one GPU race. */
+int asr_colreduce_static(const float* x, int ldx, const float* y, int ldy, int rows, int n, int gmod,
+                         float* out, int accumulate, asr_stream_t stream);
 
 /* small MLP pieces: LHUC predictor libs/lhuclstm_layers.py:402-409, conditioning prologue
  * libs/lasagne_libs/recurrent_layers.py:1209-1211.  act: 0 identity, 1 relu, 2 tanh */
