@@ -67,6 +67,7 @@ _SIGS = {
     'asr_bias_act': (i32, [fp, fp, i32, i32, i32, fp]),
     'asr_act_bwd': (i32, [fp, fp, i32, i32, i32, fp]),
     'asr_rowscale': (i32, [fp, i32, fp, i32, i32, fp, i32, i32, i32, fp]),
+    'asr_dropout': (i32, [fp, i32, fp, i32, i32, i32, f32, C.c_ulonglong, C.c_ulonglong, fp]),
     'asr_affine_rows': (i32, [fp, i32, fp, fp, fp, fp, i32, i32, i32, fp, i32, i32, i32, fp]),
     'asr_masked_mean': (i32, [fp, fp, i32, i32, i32, fp, fp]),
     'asr_masked_mean_tanh_bwd': (i32, [fp, fp, fp, i32, i32, i32, fp, fp]),

@@ -447,6 +447,61 @@ extern "C" int asr_rowscale(const float* x, int ldx, const float* s, int B, int 
     return ASR_OK;
 }
 
+// ------------------------------------------------------------------ inverted dropout
+// lasagne DropoutLayer(p) in front of every layer and of the output layer of models/gating_hyper_nets.py
+// (:276-307): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p); identity when deterministic.  Theano's MRG
+// stream cannot be reproduced, so the mask comes from a counter-based generator and is never stored:
+// Philox4x32-10 keyed by `seed`, counter = (row * ceil(n/4) + column group, `stream`), one call per 4
+// consecutive columns; the backward pass calls the same entry point on the gradient with the same
+// (seed, stream) and regenerates the mask.  keep <=> u >= p with u = (word >> 8) * 2^-24.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                      int ldy, size_t rows, int n, float p, float scale,
+                                                      unsigned long long seed, unsigned long long stream) {
+    const size_t ng = (size_t)(n + 3) / 4, tot = rows * ng;
+    const bool vec = !(n & 3) && !(ldx & 3) && !(ldy & 3) && !(((uintptr_t)x | (uintptr_t)y) & 15);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / ng;
+        const int g = (int)(i % ng);
+        unsigned w[4];
+        philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)stream, (unsigned)(stream >> 32), (unsigned)seed,
+                      (unsigned)(seed >> 32), w);
+        if (vec) {
+            f32x4 v = *(const f32x4*)(x + r * ldx + g * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((float)(w[e] >> 8) * 5.9604644775390625e-08f >= p) ? v[e] * scale : 0.f;
+            *(f32x4*)(y + r * ldy + g * 4) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = g * 4 + e;
+                if (c < n) y[r * ldy + c] = ((float)(w[e] >> 8) * 5.9604644775390625e-08f >= p) ? x[r * ldx + c] * scale : 0.f;
+            }
+        }
+    }
+}
+extern "C" int asr_dropout(const float* x, int ldx, float* y, int ldy, int rows, int n, float p,
+                           unsigned long long seed, unsigned long long stream_id, hipStream_t stream) {
+    if (rows < 0 || n <= 0 || !x || !y || !(p >= 0.f) || !(p < 1.f) || ldx < n || ldy < n) return ASR_ERR_ARG;
+    const size_t tot = (size_t)rows * ((n + 3) / 4);
+    if (!tot) return ASR_OK;
+    const int grid = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(256), 0, stream, x, ldx, y, ldy, (size_t)rows, n, p,
+                       1.0f / (1.0f - p), seed, stream_id);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
 // masked mean over time of a batch-major tensor: out[b,f] = sum_t x[b,t,f]*mask[b,t] / sum_t mask[b,t]
 // (libs/lasagne_libs/recurrent_layers.py:1211); one workgroup per (b), threads over f.
 // (masked_mean / masked_mean_tanh_bwd are the batch-major (B,T,F) cases of the strided pooling kernels below)

@@ -13,6 +13,7 @@ class GradAllReduce(object):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         net.world = self.world
+        net.dropout_rank = dist.get_rank(group) if dist.is_initialized() else 0   # every rank its own masks
         self.cuda = net.device.type == 'cuda'
         self.stream = torch.cuda.Stream(device=net.device) if self.cuda else None
         self.pending = []

@@ -266,9 +266,17 @@ class LstmPair(object):
 
     # -- TBPTT state (libs/lhuclstm_layers.py:221-228)
     def reset(self, batch_size):
+        """Zero state for a new batch; the (c, r) buffers are reused while the batch size stays the same, so
+        the steady-state window loop allocates nothing."""
         dev = self.net.device
-        self.state = [(torch.zeros(batch_size, self.N, device=dev), torch.zeros(batch_size, self.N, device=dev))
-                      if (self.stateful and d == 0) else None for d in range(self.ndir)]
+        for d in range(self.ndir):
+            if not (self.stateful and d == 0):
+                self.state[d] = None
+            elif self.state[d] is not None and self.state[d][0].shape[0] == batch_size:
+                self.state[d][0].zero_(); self.state[d][1].zero_()
+            else:
+                self.state[d] = (torch.zeros(batch_size, self.N, device=dev),
+                                 torch.zeros(batch_size, self.N, device=dev))
 
     def _buf(self, name, rows, cols, zero=False):
         return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols, zero)
@@ -331,8 +339,9 @@ class LstmPair(object):
             if self.cell_ln:
                 Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
             st = self.state[d]
-            if st is not None:
-                c['c0'] = st[0].clone(); c['r0'] = st[1].clone()
+            if st is not None:           # this window's initial state, kept for its backward pass
+                c['c0'] = self._buf('c0_%d' % d, B, N); c['r0'] = self._buf('r0_%d' % d, B, N)
+                c['c0'].copy_(st[0]); c['r0'].copy_(st[1])
                 Dd.c0 = c['c0'].data_ptr(); Dd.r0 = c['r0'].data_ptr()
             direct = (not P) and self.kind != 'lhuc'       # scan writes straight into Y's column block
             if direct:
@@ -358,8 +367,8 @@ class LstmPair(object):
                 last = T - 1
                 if self.context:
                     last = (T if T < self.context else self.context) - 1
-                self.state[d] = (c['cst'][last * B:(last + 1) * B].clone(),
-                                 c['R'][last * B:(last + 1) * B].clone())
+                self.state[d][0].copy_(c['cst'][last * B:(last + 1) * B])
+                self.state[d][1].copy_(c['R'][last * B:(last + 1) * B])
             Yd = Y[:, d * Pout:(d + 1) * Pout]
             if P and self.kind != 'lhuc':
                 ops.gemm(c['R'], dp.p('Wp'), Yd)
@@ -486,11 +495,17 @@ class LstmPair(object):
         else:
             Ra, dAb, first = R[B:], dA[:n1], dA[n1:]
         ops.gemm(Ra, dAb, dWf, ta=True)
-        if 'r0' in c:
+        if 'r0' in c and not P:
             ops.gemm(c['r0'], first, dWf, ta=True, beta=1.0)
         if P:
             ops.gemm(dp.p('Wp'), dWf, dp.g('Wh'), ta=True)
             ops.gemm(dWf, dp.p('Wh'), dp.g('Wp'), tb=True, beta=1.0)
+            if 'r0' in c:
+                # the carried hid_init = r0.W_p is a stored constant (libs/lhuclstm_layers.py:230-235): its
+                # first-step term belongs to W_h alone, not to W_p through the folded matrix
+                h0 = self._buf('h0_%d' % d, B, P)
+                ops.gemm(c['r0'], dp.p('Wp'), h0)
+                ops.gemm(h0, first, dp.g('Wh'), ta=True, beta=1.0)
         if dp.has('b'):
             ops.colreduce(dG, dp.g('b'), rows, 4 * N)
         if self.cell_ln:
@@ -619,6 +634,14 @@ class Network(object):
         # of layer l-1 (the scan is latency-bound and leaves the MFMA pipes idle)
         self.overlap = self.device.type == 'cuda' and os.environ.get('ASR_OVERLAP', '1') != '0'
         self.side = None
+        # DropoutLayer(p) in front of every layer and of the output layer (models/gating_hyper_nets.py:276-307);
+        # active when train=True (deterministic=False).  The mask is a pure function of (dropout_seed,
+        # step, rank, layer): the backward pass regenerates it, nothing is stored.
+        self.dropout = 0.0
+        self.dropout_seed = 0
+        self.dropout_rank = 0
+        self.dropout_step = 0
+        self._drop_ids = []
 
     # ---- construction -------------------------------------------------------------------------
     def add_pair(self, pair, spec_per_dir):
@@ -649,6 +672,7 @@ class Network(object):
         self.m = torch.zeros_like(self.store.p)
         self.v = torch.zeros_like(self.store.p)
         self.t_prev = 0
+        self.dropout_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x2545F4914F6CDD1D) % (1 << 64)
         self.scal = torch.zeros(16, dtype=torch.float32, device=self.device)
         self.adam_ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self.finalized = True
@@ -843,13 +867,44 @@ class Network(object):
         act = self._prep_input(x, cond)
         if self.seqsum is not None:
             self.seqsum.forward(act, T, B)
-        for pair in self.pairs:
+        drop = bool(train) and self.dropout > 0
+        if drop:
+            self.dropout_step += 1
+        self._drop_ids = []
+        for l, pair in enumerate(self.pairs):
+            if drop:
+                act = self._dropout_fwd(l, act)
             act = pair.forward(act, T, B, mask, cond, train)
+        if drop:
+            act = self._dropout_fwd(len(self.pairs), act)
         self.top = act
         logits = self.arena.mat('logits', T * B, self.C)
         ops.gemm(act, self.out.p('W'), logits, bias=self.out.p('b'))   # libs/builder_utils.py:44-45
         self.logits = logits
         return logits
+
+    def _dropout_fwd(self, l, X):
+        sid = (self.dropout_step << 20) | ((self.dropout_rank & 0xfff) << 8) | l
+        self._drop_ids.append(sid)
+        Xd = self.arena.mat('drop%d' % l, X.shape[0], X.shape[1])
+        return ops.dropout(X, Xd, X.shape[0], X.shape[1], self.dropout, self.dropout_seed, sid)
+
+    def _dropout_bwd(self, l, dX):
+        """dX: gradient wrt the dropped input of layer l (l = len(pairs): the output layer), scaled in
+        place by the regenerated mask."""
+        if l < len(self._drop_ids):
+            ops.dropout(dX, dX, dX.shape[0], dX.shape[1], self.dropout, self.dropout_seed, self._drop_ids[l])
+        return dX
+
+    def dropout_masks(self):
+        """The scaled masks keep/(1-p) of the last train-mode forward, one (T*B, width) matrix per
+        DropoutLayer (tests hand them to the oracle)."""
+        out = []
+        for l, sid in enumerate(self._drop_ids):
+            n = self.arena.bufs['drop%d' % l].numel() // (self.T * self.B)
+            ones = torch.ones(self.T * self.B, n, device=self.device)
+            out.append(ops.dropout(ones, ones, ones.shape[0], n, self.dropout, self.dropout_seed, sid))
+        return out
 
     def posteriors(self, x, mask, cond=None, log=False):
         """ff_fn body (libs/comp_graph_utils.py:321-333): (B,T,C) probabilities, or the raw logits for
@@ -871,10 +926,15 @@ class Network(object):
         B, T = self.B, self.T
         rows = T * B
         tm = target_mask.contiguous()
-        if context and context < T:
-            tm = tm.clone(); tm[:, context:] = 0
-        if delay:                                  # delayed(): o[:, delay:], libs/comp_graph_utils.py:18-24
-            tm = tm.clone(); tm[:, :delay] = 0
+        cut = context if (context and context < T) else 0
+        if cut or delay:                           # scored frames only; an arena copy, no allocation
+            eff = self.arena.get('tmask_eff', B * T).view(B, T)
+            eff.copy_(tm)
+            if cut:                                # context_tbptt(): o[:, :context], libs/comp_graph_utils.py:26-27
+                eff[:, cut:].zero_()
+            if delay:                              # delayed(): o[:, delay:], libs/comp_graph_utils.py:18-24
+                eff[:, :delay].zero_()
+            tm = eff
         target = target.contiguous()
         dl = self.arena.mat('dlogits', rows, self.C) if train else None
         row_ce = self.arena.get('row_ce', rows); row_ok = self.arena.get('row_ok', rows)
@@ -895,6 +955,7 @@ class Network(object):
         dl = self.dlogits
         dY = self.arena.mat('dtop', dl.shape[0], self.K_top)
         ops.gemm(dl, self.out.p('W'), dY, tb=True)
+        self._dropout_bwd(len(self.pairs), dY)
         with self.deferred():
             ops.gemm(self.top, dl, self.out.g('W'), ta=True)
             ops.colreduce(dl, self.out.g('b'), dl.shape[0], self.C)
@@ -902,6 +963,8 @@ class Network(object):
                 self.grad_hook(*self.param_range('out.'))
         for i in range(len(self.pairs) - 1, -1, -1):
             dY = self.pairs[i].backward(dY, need_dx=(i > 0))
+            if i > 0:
+                self._dropout_bwd(i, dY)
             if self.grad_hook:
                 with self.deferred():          # after this layer's (deferred) parameter gradients
                     self.grad_hook(*self.param_range('L%d.' % i))

@@ -2,22 +2,24 @@
   deep_projection_ln_lstm_model        models/gating_hyper_nets.py:256-307
   deep_projection_ivector_ln_model     models/gating_hyper_nets.py:384-462
   deep_projection_lstm_model           plain ProjectLSTMLayer stack (same wiring, no LN)
-Every model is bidirectional, each layer preceded by DropoutLayer(p=dropout) (identity at the only
-supported value here, dropout=0 / deterministic=True), output = SequenceDenseLayer(nonlinearity=None)
--> logits."""
+Every model is bidirectional, each layer and the output layer preceded by DropoutLayer(p=dropout)
+(reference default 0.2; active in training_fn = deterministic=False, identity in predict / ff functions:
+engine.Network._dropout_fwd), output = SequenceDenseLayer(nonlinearity=None) -> logits."""
 from . import specs
 from .engine import Network, LstmPair
 
 
 def _check_dropout(dropout):
-    if dropout not in (0, 0.0, None):
-        raise NotImplementedError('asr_amd: dropout > 0 is not implemented (parity path uses dropout=0)')
+    p = float(dropout or 0.0)
+    if not 0.0 <= p < 1.0:
+        raise ValueError('dropout must be in [0, 1), got %r' % (dropout,))
+    return p
 
 
 def deep_projection_ln_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_factors,
-                                  num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
-    _check_dropout(dropout)
+                                  num_units, grad_clipping=1, dropout=0.2, device=None, seed=0):
     net = Network(device or 'cuda:0')
+    net.dropout = _check_dropout(dropout)
     F = num_factors or num_units // 2          # recurrent_layers.py:578-580
     D = num_inputs
     for l in range(num_layers):
@@ -29,9 +31,9 @@ def deep_projection_ln_lstm_model(input_var, mask_var, num_inputs, num_outputs, 
 
 
 def deep_projection_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_factors,
-                               num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
-    _check_dropout(dropout)
+                               num_units, grad_clipping=1, dropout=0.2, device=None, seed=0):
     net = Network(device or 'cuda:0')
+    net.dropout = _check_dropout(dropout)
     F = num_factors or num_units // 2
     D = num_inputs
     for l in range(num_layers):
@@ -43,14 +45,14 @@ def deep_projection_lstm_model(input_var, mask_var, num_inputs, num_outputs, num
 
 
 def deep_projection_ivector_ln_model(input_var, cond_var, mask_var, num_inputs, num_outputs, num_layers,
-                                     num_conds, num_factors, num_units, grad_clipping=1, dropout=0.0,
+                                     num_conds, num_factors, num_units, grad_clipping=1, dropout=0.2,
                                      cond_dim=100, device=None, seed=0):
     """-> (output_layer, cond_layer_list).  The first `num_conds` layers are
     InputCondLayerNormProjectLSTMLayer (hidden width num_units/2, recurrent_layers.py:1120,1141),
     the rest ProjectLSTMLayer(num_factors) (models/gating_hyper_nets.py:413-449).  The i-vector input
     layer is hard-wired to 100 dims in the reference (:400); `cond_dim` exposes it."""
-    _check_dropout(dropout)
     net = Network(device or 'cuda:0')
+    net.dropout = _check_dropout(dropout)
     net.uses_cond = True
     D = num_inputs
     cond_layers = []
@@ -70,8 +72,7 @@ def deep_projection_ivector_ln_model(input_var, cond_var, mask_var, num_inputs, 
 
 # ------------------------------------------------------------------------------------------------
 # The remaining LSTM builders of models/gating_hyper_nets.py on the generic recurrent_layers.py
-# family (asr_amd/engine_rec.py).  Same names / argument order / defaults except `dropout`, whose
-# reference default 0.2 is only usable at inference (deterministic=True): training needs dropout=0.
+# family (asr_amd/engine_rec.py).  Same names / argument order / defaults.
 class CondLayerHandle(object):
     """What the reference appends to cond_layer_list: one entry per direction with get_sample_feat()
     (libs/lasagne_libs/recurrent_layers.py:1337-1338)."""
@@ -87,7 +88,7 @@ def _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dr
                device=None, seed=0, training_dropout_ok=False):
     from .engine_rec import RecPair
     net = Network(device or 'cuda:0')
-    net.dropout = dropout
+    net.dropout = _check_dropout(dropout)
     ndir = 2 if is_bidir else 1
     if cond_cls and specs.REC_CLASSES[cond_cls]['cond'] == 'ext':
         net.uses_cond = True
@@ -107,84 +108,74 @@ def _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dr
 
 
 def deep_projection_cond_ln_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_conds,
-                                  num_factors, num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
+                                  num_factors, num_units, grad_clipping=1, dropout=0.2, device=None, seed=0):
     """models/gating_hyper_nets.py:309-382 -> (output_layer, cond_layer_list)."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'ProjectLSTMLayer',
                       'CondLayerNormProjectLSTMLayer', num_conds, num_factors, device=device, seed=seed)
 
 
 def deep_projection_max_cond_ln_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_conds,
-                                      num_factors, num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
+                                      num_factors, num_units, grad_clipping=1, dropout=0.2, device=None, seed=0):
     """:544-617."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'ProjectLSTMLayer',
                       'MaxCondLayerNormProjectLSTMLayer', num_conds, num_factors, device=device, seed=seed)
 
 
 def deep_projection_max_ivector_ln_model(input_var, cond_var, mask_var, num_inputs, num_outputs, num_layers,
-                                         num_conds, num_factors, num_units, grad_clipping=1, dropout=0.0,
+                                         num_conds, num_factors, num_units, grad_clipping=1, dropout=0.2,
                                          cond_dim=100, device=None, seed=0):
     """:694-772 (i-vector input hard-wired to 100 dims at :710; `cond_dim` exposes it)."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'ProjectLSTMLayer',
                       'MaxInputCondLayerNormProjectLSTMLayer', num_conds, num_factors, cond_dim=cond_dim,
                       device=device, seed=seed)
 
 
 def deep_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
-                    dropout=0.0, device=None, seed=0):
+                    dropout=0.2, device=None, seed=0):
     """:858-906."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LSTMLayer',
                       device=device, seed=seed)[0]
 
 
 def deep_ln_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
-                       dropout=0.0, device=None, seed=0):
+                       dropout=0.2, device=None, seed=0):
     """:908-956."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LayerNormLSTMLayer',
                       device=device, seed=seed)[0]
 
 
 def deep_cond_ln_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_factors, num_conds,
-                       num_units, grad_clipping=1, dropout=0.0, device=None, seed=0):
+                       num_units, grad_clipping=1, dropout=0.2, device=None, seed=0):
     """:958-1029 (note the reference's argument order: num_factors BEFORE num_conds)."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LSTMLayer',
                       'CondLayerNormLSTMLayer', num_conds, num_factors, device=device, seed=seed)
 
 
 def deep_ivector_ln_model(input_var, cond_var, mask_var, num_inputs, num_outputs, num_layers, num_conds,
-                          num_factors, num_units, grad_clipping=1, dropout=0.0, cond_dim=100, device=None, seed=0):
+                          num_factors, num_units, grad_clipping=1, dropout=0.2, cond_dim=100, device=None, seed=0):
     """:1031-1107."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, 'LSTMLayer',
                       'InputCondLayerNormLSTMLayer', num_conds, num_factors, cond_dim=cond_dim, device=device,
                       seed=seed)
 
 
 def deep_prj_lstm_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, num_prjs,
-                           grad_clipping=1, dropout=0.0, device=None, seed=0):
+                           grad_clipping=1, dropout=0.2, device=None, seed=0):
     """:1113-1164."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'ProjectLSTM_v0_1_Layer', num_prjs=num_prjs, device=device, seed=seed)[0]
 
 
 def deep_prj_lstm_ln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, num_prjs,
-                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+                              grad_clipping=1, dropout=0.2, device=None, seed=0):
     """:1166-1217."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormProjectLSTM_v0_1_Layer', num_prjs=num_prjs, device=device, seed=seed)[0]
 
 
 def deep_prj_lstm_ln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, num_prjs,
-                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+                              grad_clipping=1, dropout=0.2, device=None, seed=0):
     """:1219-1270 (per-gate layer norm)."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormProjectLSTM_v0_2_Layer', num_prjs=num_prjs, device=device, seed=seed)[0]
 
@@ -194,69 +185,61 @@ def _dln(num_layers, num_conds):
 
 
 def deep_prj_lstm_dln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_units, num_prjs, num_factors,
-                               num_layers, num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+                               num_layers, num_conds=-1, grad_clipping=0.0, dropout=0.2, device=None, seed=0):
     """:1272-1352."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormProjectLSTM_v0_1_Layer', 'CondLayerNormProjectLSTM_v0_1_Layer',
                       _dln(num_layers, num_conds), num_factors, num_prjs, device=device, seed=seed)
 
 
 def deep_prj_lstm_dln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_units, num_prjs, num_factors,
-                               num_layers, num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+                               num_layers, num_conds=-1, grad_clipping=0.0, dropout=0.2, device=None, seed=0):
     """:1354-1436."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormProjectLSTM_v0_2_Layer', 'CondLayerNormProjectLSTM_v0_2_Layer',
                       _dln(num_layers, num_conds), num_factors, num_prjs, device=device, seed=seed)
 
 
 def deep_reg_lstm_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
-                           dropout=0.0, device=None, seed=0):
+                           dropout=0.2, device=None, seed=0):
     """:1438-1486."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'RegularLSTM_v0_1_Layer', device=device, seed=seed)[0]
 
 
 def deep_reg_lstm_ln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units,
-                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+                              grad_clipping=1, dropout=0.2, device=None, seed=0):
     """:1488-1536."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormRegularLSTM_v0_1_Layer', device=device, seed=seed)[0]
 
 
 def deep_reg_lstm_ln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units,
-                              grad_clipping=1, dropout=0.0, device=None, seed=0):
+                              grad_clipping=1, dropout=0.2, device=None, seed=0):
     """:1538-1586 (per-gate layer norm)."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormRegularLSTM_v0_2_Layer', device=device, seed=seed)[0]
 
 
 def deep_reg_lstm_dln_model_v1(input_var, mask_var, num_inputs, num_outputs, num_units, num_factors, num_layers,
-                               num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+                               num_conds=-1, grad_clipping=0.0, dropout=0.2, device=None, seed=0):
     """:1588-1663."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormRegularLSTM_v0_1_Layer', 'CondLayerNormRegularLSTM_v0_1_Layer',
                       _dln(num_layers, num_conds), num_factors, device=device, seed=seed)
 
 
 def deep_reg_lstm_dln_model_v2(input_var, mask_var, num_inputs, num_outputs, num_units, num_factors, num_layers,
-                               num_conds=-1, grad_clipping=0.0, dropout=0.0, device=None, seed=0):
+                               num_conds=-1, grad_clipping=0.0, dropout=0.2, device=None, seed=0):
     """:1665-1743."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'LayerNormRegularLSTM_v0_2_Layer', 'CondLayerNormRegularLSTM_v0_2_Layer',
                       _dln(num_layers, num_conds), num_factors, device=device, seed=seed)
 
 
 def uni_lstm_model(input_var, mask_var, num_inputs, num_outputs, num_layers, num_units, grad_clipping=1,
-                   dropout=0.0, device=None, seed=0):
+                   dropout=0.2, device=None, seed=0):
     """:1745-1784 (the only unidirectional builder of the file)."""
-    _check_dropout(dropout)
     return _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout,
                       'RegularLSTM_v0_1_Layer', is_bidir=False, device=device, seed=seed)[0]
 

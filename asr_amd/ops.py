@@ -93,6 +93,13 @@ def rowscale(x, ldx, s, B, relu, y, ldy, rows, n):
     return y
 
 
+def dropout(x, y, rows, n, p, seed, stream_id):
+    """y = x * keep/(1-p) with the Philox mask of (seed, stream_id); in place when y is x."""
+    check(_lib.lib().asr_dropout(_p(x), x.stride(0), _p(y), y.stride(0), rows, n, float(p), int(seed),
+                                 int(stream_id), _s()), 'asr_dropout')
+    return y
+
+
 def affine_rows(x, ldx, a, c0, c1, mask, B, y, ldy, rows, n):
     check(_lib.lib().asr_affine_rows(_p(x), ldx, _p(a), _p(c0), _p(c1), _p(mask), mask.stride(0), mask.stride(1), B,
                                      _p(y), ldy, rows, n, _s()), 'asr_affine_rows')

@@ -76,6 +76,12 @@ int asr_bias_act(float* x, const float* bias, int rows, int n, int act, asr_stre
 int asr_act_bwd(float* dy, const float* y, int rows, int n, int act, asr_stream_t stream);
 int asr_rowscale(const float* x, int ldx, const float* s, int B, int relu, float* y, int ldy, int rows,
                  int n, asr_stream_t stream);                 /* LHUC, libs/lhuclstm_layers.py:461-462 */
+/* Inverted dropout, lasagne DropoutLayer(p) as models/gating_hyper_nets.py:276-307 places it (in front of every
+ * layer and of the output layer; identity when deterministic): y = x * keep / (1-p).  keep comes from
+ * Philox4x32-10(key = seed, counter = (row*ceil(n/4) + column/4, stream_id)), u = (word >> 8) * 2^-24, keep <=>
+ * u >= p; the mask is never stored: the backward pass applies the same call to the gradient.  x == y allowed. */
+int asr_dropout(const float* x, int ldx, float* y, int ldy, int rows, int n, float p, unsigned long long seed,
+                unsigned long long stream_id, asr_stream_t stream);
 /* y[r,:] = a[b,:]*x[r,:] + c0[b,:] + mask[b,t]*c1[b,:] over time-major rows r = t*B + b: the gradient of the
  * inter / intra variance costs on the inner hidden sequences, scripts/hypernets/exp_prj_hyper.py:108-124 */
 int asr_affine_rows(const float* x, int ldx, const float* a, const float* c0, const float* c1, const float* mask,

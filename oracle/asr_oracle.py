@@ -118,6 +118,22 @@ def lstm_scan_fwd(xin, mask, p, spec, c0=None, h0=None):
     return hid, cell, cache
 
 
+def carried_r(cache, spec, r0=None):
+    """(T,B,N): the masked pre-projection state r_t = o*tanh(outcell) that lstm_scan_fwd carried (its own
+    state is h = r.W_p; the HIP scan carries r and folds W_p into the recurrent matrix)."""
+    T = len(cache)
+    order = range(T - 1, -1, -1) if spec.get('backwards') else range(T)
+    r = None
+    out = [None] * T
+    for t in order:
+        m, rn = cache[t][0], cache[t][8]
+        if r is None:
+            r = np.zeros_like(rn) if r0 is None else r0
+        r = np.where(m, rn, r)
+        out[t] = r
+    return np.stack(out)
+
+
 def lstm_scan_bwd(dhid, cache, p, spec, dcell=None):
     """BPTT through lstm_scan_fwd.  dhid (T,B,P) = dLoss/d hid_out.  Returns dxin, grads, (dc0, dh0)."""
     T = dhid.shape[0]
@@ -756,7 +772,9 @@ class ProjectLSTMLayerO(OracleLayer):
         self.Wx = _stack(self.P, 'W_in_to_{}', GATES_REC)
         xin = self.x @ self.Wx                          # :431 (+b_stacked: same sum, added in step)
         self.p = self._p()
-        hid, _, self.cache = lstm_scan_fwd(xin, m, self.p, self.spec)
+        c0, h0 = getattr(self, 'init', None) or (None, None)     # tests only: start a window from a given state
+        hid, self.cell_seq, self.cache = lstm_scan_fwd(xin, m, self.p, self.spec, c0, h0)
+        self.hid_seq = hid
         return _tm(hid)
 
     def backward(self, dy):
@@ -811,7 +829,9 @@ class InputCondLayerNormProjectLSTMLayerO(OracleLayer):
         xin = self.x @ self.Wx + beta[None]                             # :1233
         self.p = dict(W_h=_stack(P, 'W_hid_to_{}', GATES_REC), W_p=P['W_hid_prj'], b=None,
                       alpha_in=alpha_in, alpha_hid=alpha_hid)
-        hid, _, self.cache = lstm_scan_fwd(xin, m, self.p, self.spec)
+        c0, h0 = getattr(self, 'init', None) or (None, None)     # tests only: start a window from a given state
+        hid, self.cell_seq, self.cache = lstm_scan_fwd(xin, m, self.p, self.spec, c0, h0)
+        self.hid_seq = hid
         return _tm(hid)
 
     def get_sample_feat(self):                                          # :1337-1338
@@ -1109,6 +1129,36 @@ def log_softmax(a):
     return a - np.log(np.exp(a).sum(axis=-1, keepdims=True))
 
 
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator
+    asr_dropout uses -- Theano's MRG31k3p stream of lasagne's DropoutLayer cannot be reproduced).
+    counter: (..., 4) uint32, key: (2,) uint32 -> (..., 4) uint32."""
+    c = [np.asarray(counter[..., i], np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c[0]; p1 = M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0 = (k0 + W0) & MASK; k1 = (k1 + W1) & MASK
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def dropout_mask(rows, n, p, seed, stream_id):
+    """The scaled mask keep/(1-p), (rows, n), that asr_dropout applies for (seed, stream_id): one Philox
+    call per 4 consecutive columns of a row, counter = (row*ceil(n/4) + group, stream_id), keep <=>
+    (word >> 8) * 2^-24 >= p (float32 comparison)."""
+    ng = (n + 3) // 4
+    idx = np.arange(rows * ng, dtype=np.uint64)
+    ctr = np.stack([idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32),
+                    np.full_like(idx, stream_id & 0xFFFFFFFF), np.full_like(idx, (stream_id >> 32) & 0xFFFFFFFF)], -1)
+    w = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    keep = (u >= np.float32(p)).reshape(rows, ng * 4)[:, :n]
+    return keep.astype(np.float32) * (np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+
 def softmax_ce(logits, target, target_mask):
     """libs/comp_graph_utils.py:29-45 (probabilities -> categorical_crossentropy) and
     scripts/hypernets/exp_prj_ln_lstm_fix.py:84-95 (logits -> log-softmax -> one-hot CE): the same
@@ -1256,7 +1306,11 @@ class OracleNetwork(object):
     def tbptt_layers(self):
         return [p[0] for p in self.layers if getattr(p[0], 'stateful', False)]
 
-    def forward(self, x, mask, cond=None):
+    def forward(self, x, mask, cond=None, drop=None):
+        """drop: None (deterministic) or the L+1 scaled masks keep/(1-p), (B,T,width) each, of the
+        DropoutLayers in front of every layer and of the output layer (models/gating_hyper_nets.py:276-307;
+        lasagne DropoutLayer: input * mask / (1-p))."""
+        self.drop = None if drop is None else [np.asarray(d, self.dtype) for d in drop]
         x = np.asarray(x, self.dtype); mask = np.asarray(mask, self.dtype)
         if cond is not None:
             cond = np.asarray(cond, self.dtype)
@@ -1272,12 +1326,14 @@ class OracleNetwork(object):
             out = a[-1] @ ss[2 * nl] + ss[2 * nl + 1]
             self.ss_acts = a
             cond = out.mean(axis=1)[:, None, :]          # SeqSumLHUCLSTMLayer reads it as the embedding
-        for f, b in self.layers:
-            yf = f.forward(self.acts[-1], mask, cond)
+        for l, (f, b) in enumerate(self.layers):
+            xin = self.acts[-1] if self.drop is None else self.acts[-1] * self.drop[l]
+            yf = f.forward(xin, mask, cond)
             self.split.append(yf.shape[-1])
-            y = yf if b is None else np.concatenate([yf, b.forward(self.acts[-1], mask, cond)], -1)
+            y = yf if b is None else np.concatenate([yf, b.forward(xin, mask, cond)], -1)
             self.acts.append(y)
-        self.logits = self.acts[-1] @ self.W + self.b      # libs/builder_utils.py:44-45
+        self.top = self.acts[-1] if self.drop is None else self.acts[-1] * self.drop[len(self.layers)]
+        self.logits = self.top @ self.W + self.b           # libs/builder_utils.py:44-45
         return self.logits
 
     def posteriors(self, x, mask, cond=None):
@@ -1286,10 +1342,10 @@ class OracleNetwork(object):
         lg = self.forward(x, mask, cond)
         return np.exp(log_softmax(lg)) if self.desc['output'] == 'softmax' else lg
 
-    def loss_and_grads(self, x, mask, target, target_mask, cond=None, context=0, aux=None):
+    def loss_and_grads(self, x, mask, target, target_mask, cond=None, context=0, aux=None, drop=None):
         """aux = (w_inter, w_intra): adds the exp_prj_hyper.py costs on the inner hidden sequences of the first
         (ProjectionHyper) layer pair to the loss; self.aux_costs then holds (inter, intra)."""
-        lg = self.forward(x, mask, cond)
+        lg = self.forward(x, mask, cond, drop)
         for pair in self.layers:
             for l in pair:
                 if l is not None and hasattr(l, 'd_inner'):
@@ -1304,12 +1360,14 @@ class OracleNetwork(object):
             tm = tm.copy(); tm[:, context:] = 0
         ce_cost, ce_sum, pred, dl = softmax_ce(lg, np.asarray(target), tm)
         B, T, C = lg.shape
-        top = self.acts[-1]
+        top = self.top
         gW = top.reshape(B * T, -1).T @ dl.reshape(B * T, C)
         gb = dl.sum((0, 1))
         dy = dl @ self.W.T
+        if self.drop is not None:
+            dy = dy * self.drop[len(self.layers)]
         grads_rev = []
-        for (f, b), nf in zip(reversed(self.layers), reversed(self.split)):
+        for li, ((f, b), nf) in enumerate(zip(reversed(self.layers), reversed(self.split))):
             if b is None:
                 dx = f.backward(dy)
                 grads_rev.append([f.grads[n] for n in f.param_names])
@@ -1319,6 +1377,8 @@ class OracleNetwork(object):
                 grads_rev.append([f.grads[n] for n in f.param_names] +
                                  [b.grads[n] for n in b.param_names])
             dy = dx
+            if self.drop is not None:
+                dy = dy * self.drop[len(self.layers) - 1 - li]
         grads = [g for lg_ in reversed(grads_rev) for g in lg_] + [gW, gb]
         if self.seqsum is not None:
             ss = self.seqsum; nl = len(ss) // 2 - 1

@@ -163,3 +163,20 @@ def test_hip_path_matches_golden_tbptt():
         gmax = max(np.max(np.abs(z['w%d_g%03d' % (w, i)])) for i in range(n))
         for i, g in enumerate(net.get_all_grad_values()):
             assert relmax(g, z['w%d_g%03d' % (w, i)], floor=1e-3 * gmax) < 1e-4, (w, i)
+
+
+def test_philox_known_answers_and_dropout_mask():
+    """The generator behind asr_dropout, pinned to the published Random123 known-answer vectors for
+    philox4x32-10 (kat_vectors: zero counter/key, all-ones, and the digits-of-pi case)."""
+    from oracle import asr_oracle as O
+    z = O.philox4x32_10(np.zeros((1, 4), np.uint32), (0, 0))[0]
+    assert [int(v) for v in z] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = O.philox4x32_10(np.full((1, 4), 0xffffffff, np.uint32), (0xffffffff, 0xffffffff))[0]
+    assert [int(v) for v in f] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    p = O.philox4x32_10(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], np.uint32), (0xa4093822, 0x299f31d0))[0]
+    assert [int(v) for v in p] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    m = O.dropout_mask(2000, 37, 0.2, 12345, 7)
+    assert m.shape == (2000, 37) and set(np.unique(m).tolist()) == {0.0, np.float32(1.25)}
+    assert abs((m > 0).mean() - 0.8) < 0.01 and np.array_equal(m, O.dropout_mask(2000, 37, 0.2, 12345, 7))
+    assert not np.array_equal(m, O.dropout_mask(2000, 37, 0.2, 12345, 8))
+    assert (O.dropout_mask(10, 5, 0.0, 1, 1) == 1.0).all()

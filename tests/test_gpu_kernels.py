@@ -74,6 +74,34 @@ def test_colreduce_ragged_groups():
         assert relerr(out.cpu().numpy(), ref) < 1e-5, (rows, gmod)
 
 
+def test_dropout_mask_is_philox_and_inverted():
+    """asr_dropout against the oracle's numpy Philox4x32-10 (pinned to the Random123 known answers in
+    tests/test_golden.py): bit-identical masks, vectorised and ragged widths, strided rows; keep rate and the
+    1/(1-p) scaling checked statistically."""
+    from asr_amd import ops
+    rng = np.random.default_rng(11)
+    for rows, n, ld, p, seed, sid in ((257, 64, 64, 0.2, 0x123456789ABCDEF, 5), (33, 37, 40, 0.5, 7, (3 << 20) | 2),
+                                      (64, 123, 123, 0.2, 2 ** 63 + 11, 2 ** 40 + 9), (5, 8, 12, 0.0, 1, 1)):
+        x = rng.standard_normal((rows, ld)).astype(np.float32)
+        dx = torch.from_numpy(x).cuda()
+        y = torch.full((rows, ld), -7.0, device='cuda')
+        ops.dropout(dx[:, :n], y[:, :n], rows, n, p, seed, sid)
+        mk = O.dropout_mask(rows, n, p, seed, sid)
+        got = y.cpu().numpy()
+        assert np.array_equal(got[:, :n], x[:, :n] * mk), (rows, n)
+        assert (got[:, n:] == -7.0).all()
+        ops.dropout(dx[:, :n], dx[:, :n], rows, n, p, seed, sid)          # in place = what the backward does
+        assert np.array_equal(dx.cpu().numpy()[:, :n], got[:, :n])
+    ones = torch.ones(4096, 512, device='cuda')
+    m = ops.dropout(ones, torch.empty_like(ones), 4096, 512, 0.2, 99, 1).cpu().numpy()
+    assert set(np.unique(m).tolist()) == {0.0, np.float32(1.25)}
+    keep = (m > 0).mean()
+    assert abs(keep - 0.8) < 4 * np.sqrt(0.16 / m.size) and abs(m.mean() - 1.0) < 2e-3
+    assert abs((m[:, ::4] > 0).mean() - 0.8) < 2e-3 and abs((m[::2] > 0).mean() - 0.8) < 2e-3
+    m2 = ops.dropout(ones, torch.empty_like(ones), 4096, 512, 0.2, 99, 2).cpu().numpy()
+    assert abs(((m > 0) == (m2 > 0)).mean() - (0.64 + 0.04)) < 2e-3        # independent streams
+
+
 def test_ln_rows_per_gate():
     """groups=4 (gate_ln / sample_gate_ln): the kernel works on gate-interleaved columns (col = unit*4 +
     gate), the oracle on the reference's gate-major blocks."""

@@ -1,0 +1,213 @@
+"""Parity at the REAL sequence lengths of the configs the metric is quoted on (T up to ~2300), against the
+float64 oracle -- not the truncated time axes of test_gpu_fullsize.py.  Two views, both recorded:
+
+  KERNEL parity at fixed bounds (2e-5 of the tensor maximum forward, 1e-4 backward), one layer at a time,
+  teacher-forced: each layer pair gets the float64 oracle's own input of that layer (and a seeded upstream
+  gradient), so an error cannot be amplified by the layers above or below.
+    cfg3 (4x512 HyperLSTM, the headline workload): every layer over the whole length, T = 2262 steps of
+         the persistent scan in one launch (buffer wrap, step parity, walking pointers, 16-row chunking).
+    cfg2 / cfg4 (4-layer LN-LSTMP stacks): every layer over the whole length in windows of 40 frames, each
+         layer-direction started from the oracle's state at the window edge (the descriptor's c0 / r0);
+         forward on every window, backward on a spread of windows.
+  END-TO-END cfg3 at full length, free-running through 4 layers x 2262 steps: posteriors, loss, argmax and
+  every gradient against float64, next to what the SAME restatement loses when it is run in float32 numpy
+  (the rounding-noise amplification of the network itself, which no fp32 implementation -- the reference's
+  Theano run included -- can beat).  The bound there is max(fixed bound, 3 x that floor); both are recorded.
+Measured errors are appended to gpurun_out/parity_r02.jsonl (committed as profiles/parity_r02.json)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from asr_amd import workloads
+from oracle import asr_oracle as O
+from test_gpu_fullsize import build_cfg, _t
+from test_gpu_parity import perturb_params, relerr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_F, TOL_G = 2e-5, 1e-4
+
+
+def _record(**kw):
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity_r02.jsonl'), 'a') as f:
+            f.write(json.dumps(kw) + '\n')
+
+
+def _grad_errs(got, want, names, top=None):
+    gmax = max(np.max(np.abs(g)) for g in want)
+    errs = []
+    for k, (n, g, og) in enumerate(zip(names, got, want)):
+        assert g.shape == og.shape, (n, g.shape, og.shape)
+        errs.append((float(np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax)), '%d:%s' % (k, n)))
+    errs.sort(reverse=True)
+    if top is not None:
+        top.extend(errs[:6])
+    return errs[0]
+
+
+def _tm(a):
+    """(B,T,K) numpy -> time-major (T*B,K) float32 device matrix"""
+    B, T, K = a.shape
+    return _t(np.ascontiguousarray(a.transpose(1, 0, 2).reshape(T * B, K).astype(np.float32)))
+
+
+def _bt(t, B, T):
+    return t.cpu().numpy().reshape(T, B, -1).transpose(1, 0, 2)
+
+
+def _layer_case(net, pair, opair, x_in, mask, cond, want_out, rng, backward=True):
+    """One layer pair on the oracle's input of that layer.  -> (forward err, worst gradient err, name)."""
+    B, T, _ = x_in.shape
+    dm = _t(mask)
+    dc = _t(cond) if cond is not None else None
+    Y = pair.forward(_tm(x_in), T, B, dm, dc, True)
+    net.check_status()
+    valid = mask[:, :, None] > 0
+    ef = relerr(_bt(Y, B, T) * valid, want_out * valid)
+    if not backward:
+        return ef, 0.0, None
+    dY = rng.standard_normal(want_out.shape) * valid
+    dX = pair.backward(_tm(dY), need_dx=True)
+    net.join_deferred()
+    net.check_status()
+    nf = want_out.shape[-1] // 2
+    odx = opair[0].backward(dY[..., :nf]) + opair[1].backward(dY[..., nf:])
+    got = [_bt(dX, B, T)] + [v for dp in pair.dirs for _, v in dp.dump_ref(grads=True)]
+    want = [odx] + [lay.grads[n] for lay in opair for n in lay.param_names]
+    names = ['dX'] + [('fwd.' if k == 0 else 'bwd.') + n for k, lay in enumerate(opair) for n in lay.param_names]
+    eg, gname = _grad_errs(got, want, names)
+    return ef, eg, gname
+
+
+@pytest.mark.timeout(1100)
+def test_cfg3_full_length_vs_oracle():
+    net, _ = build_cfg(3)
+    vals = perturb_params(net, 60, 0.02)
+    b = workloads.make_batch(3, 16, seed_offset=0)
+    B, T = b['mask'].shape
+    assert T > 2000
+    x, m, y = _t(b['x']), _t(b['mask']), _t(b['y'])
+    post = net.posteriors(x, m).cpu().numpy()
+    net.check_status()
+    ce, ok, pred = net.loss(x, m, y, m)
+    net.backward()
+    net.check_status()
+    grads = net.get_all_grad_values()
+    names = [n for n, _ in net.param_names_shapes()]
+    t0 = time.time()
+    onet = O.OracleNetwork(net.describe(), vals)
+    _, os_, opred, ograds = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    opost = np.exp(O.log_softmax(onet.logits))
+    secs = time.time() - t0
+    valid = b['mask'][:, :, None] > 0
+    ef = relerr(post * valid, opost * valid)
+    lp, olp = np.log(post[valid[:, :, 0]]), np.log(opost[valid[:, :, 0]])
+    elp = float(np.max(np.abs(lp - olp)) / np.max(np.abs(olp)))
+    ece = abs(ce.item() - os_) / abs(os_)
+    top = []
+    eg, gname = _grad_errs(grads, ograds, names, top)
+    agree = float(((pred.cpu().numpy() == opred) | (b['mask'] == 0)).mean())
+    # kernel parity, one layer at a time on the oracle's own layer inputs (fixed bounds)
+    rng = np.random.default_rng(77)
+    per_layer = []
+    for l, (pair, opair) in enumerate(zip(net.pairs, onet.layers)):
+        lf, lg, lname = _layer_case(net, pair, opair, onet.acts[l], b['mask'], None, onet.acts[l + 1], rng)
+        per_layer.append(dict(layer=l, forward_rel=lf, worst_grad_rel=lg, worst_grad=lname))
+        print('cfg3 layer %d alone, T=%d: output %.2e, worst gradient %.2e (%s)' % (l, T, lf, lg, lname))
+    # what float32 arithmetic itself loses on this network (same restatement, numpy float32)
+    del onet
+    o32 = O.OracleNetwork(net.describe(), vals, dtype=np.float32)
+    _, _, _, g32 = o32.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    p32 = np.exp(O.log_softmax(o32.logits.astype(np.float64)))
+    floor_f = relerr(p32 * valid, opost * valid)
+    floor_g, _ = _grad_errs(g32, ograds, names)
+    _record(cfg=3, T=int(T), B=16, frames=int(b['frames']), posteriors_rel=ef, logpost_rel=elp, ce_rel=ece,
+            worst_grad_rel=eg, worst_grad=gname, argmax_agree=agree, fixed_bound_f=TOL_F, fixed_bound_g=TOL_G,
+            fp32_floor_posteriors=floor_f, fp32_floor_grad=floor_g, per_layer=per_layer, oracle_seconds=secs,
+            mode='end to end free-running at full length; per_layer = each layer on the oracle input of that layer')
+    print('cfg3 T=%d end to end: posteriors %.2e (fp32 floor %.2e), log-posteriors %.2e, CE %.2e, worst gradient '
+          '%.2e (%s; fp32 floor %.2e), oracle %.0f s' % (T, ef, floor_f, elp, ece, eg, gname, floor_g, secs))
+    print('worst gradients:', top)
+    for r in per_layer:
+        assert r['forward_rel'] < TOL_F and r['worst_grad_rel'] < TOL_G, r
+    assert ece < TOL_F and elp < TOL_F
+    assert ef < max(TOL_F, 3 * floor_f), (ef, floor_f)
+    assert eg < max(TOL_G, 3 * floor_g), (gname, eg, floor_g)
+    assert agree > 0.9999
+
+
+def _edge_states(layer, t0, t1):
+    """(c, r) float64 the layer-direction holds when it enters the window [t0, t1) of the full run."""
+    c_seq, r_seq = layer.cell_seq, layer.r_seq
+    T = c_seq.shape[0]
+    if layer.spec.get('backwards'):
+        return (c_seq[t1], r_seq[t1]) if t1 < T else (np.zeros_like(c_seq[0]), np.zeros_like(r_seq[0]))
+    return (c_seq[t0 - 1], r_seq[t0 - 1]) if t0 > 0 else (np.zeros_like(c_seq[0]), np.zeros_like(r_seq[0]))
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize('cfg', [2, 4])
+def test_ln_stacks_full_length_teacher_forced_windows(cfg):
+    WIN = 40
+    net, ck = build_cfg(cfg)
+    vals = perturb_params(net, 60 + cfg, 0.02)
+    b = workloads.make_batch(cfg, 16, seed_offset=0)
+    T = b['x'].shape[1]
+    assert T > 1000
+    cond = b.get(ck)
+    t_or = time.time()
+    onet = O.OracleNetwork(net.describe(), vals)
+    onet.forward(b['x'], b['mask'], cond)
+    for pair in onet.layers:
+        for lay in pair:
+            lay.r_seq = O.carried_r(lay.cache, lay.spec)
+            lay.cache = None                              # free the per-step caches of the full run
+    secs_full = time.time() - t_or
+    wnet = O.OracleNetwork(net.describe(), vals)          # runs one (layer, window) at a time
+    lens = b['lengths']
+    starts = list(range(0, T, WIN))
+    grad_windows = set(starts[::max(1, len(starts) // 8)][:9])
+    rng = np.random.default_rng(78)
+    worst = [dict(layer=l, forward_rel=0.0, worst_grad_rel=0.0, worst_grad=None) for l in range(len(net.pairs))]
+    nwin = ngw = 0
+    for t0 in starts:
+        t1 = min(t0 + WIN, T)
+        rows = np.nonzero(lens > t0)[0]                   # utterances still running
+        if len(rows) == 0:
+            break
+        mw = b['mask'][rows, t0:t1]
+        cw = cond[rows, t0:t1] if cond is not None else None
+        nwin += 1
+        ngw += t0 in grad_windows
+        for l, (pair, opair, wpair) in enumerate(zip(net.pairs, onet.layers, wnet.layers)):
+            xin = onet.acts[l][rows, t0:t1]
+            want = onet.acts[l + 1][rows, t0:t1]
+            for d in range(2):
+                c0, r0 = _edge_states(opair[d], t0, t1)
+                c0, r0 = c0[rows], r0[rows]
+                pair.state[d] = (_t(c0.astype(np.float32)), _t(r0.astype(np.float32)))
+                wpair[d].init = (c0, r0 @ wpair[d].P['W_hid_prj'])
+            wout = np.concatenate([wpair[0].forward(xin, mw, cw), wpair[1].forward(xin, mw, cw)], -1)
+            valid = mw[:, :, None] > 0
+            assert relerr(wout * valid, want * valid) < 1e-9          # the windowed oracle IS the full run
+            lf, lg, lname = _layer_case(net, pair, wpair, xin, mw, cw, want, rng, backward=t0 in grad_windows)
+            w = worst[l]
+            w['forward_rel'] = max(w['forward_rel'], lf)
+            if lg > w['worst_grad_rel']:
+                w['worst_grad_rel'], w['worst_grad'] = lg, lname
+    for pair in net.pairs:
+        pair.state = [None] * pair.ndir
+    _record(cfg=cfg, T=int(T), B=16, frames=int(b['frames']), window=WIN, windows=nwin, grad_windows=int(ngw),
+            per_layer=worst, fixed_bound_f=TOL_F, fixed_bound_g=TOL_G, oracle_seconds=secs_full,
+            mode='per layer, teacher-forced windows over the full length (input and edge state from the float64 oracle)')
+    for w in worst:
+        print('cfg%d layer %d, T=%d in %d windows of %d (%d with backward): output %.2e, worst gradient %.2e (%s)'
+              % (cfg, w['layer'], T, nwin, WIN, ngw, w['forward_rel'], w['worst_grad_rel'], w['worst_grad']))
+    for w in worst:
+        assert w['forward_rel'] < TOL_F and w['worst_grad_rel'] < TOL_G, w

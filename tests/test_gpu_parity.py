@@ -306,9 +306,9 @@ def test_ln_backward_2d_decomposition_n128(kind):
     if kind == 'ln':
         net = G.deep_projection_ln_lstm_model(None, None, 11, 13, 2, None, 128, 1.0, 0.0, device=_dev(), seed=81)
     elif kind == 'gate_ln':                 # per-gate statistics (LayerNormProjectLSTM_v0_2_Layer)
-        net = G.deep_prj_lstm_ln_model_v2(None, None, 11, 13, 2, 128, 64, grad_clipping=1.0, device=_dev(), seed=85)
+        net = G.deep_prj_lstm_ln_model_v2(None, None, 11, 13, 2, 128, 64, grad_clipping=1.0, dropout=0.0, device=_dev(), seed=85)
     elif kind == 'sample_gate_ln':          # CondLayerNormProjectLSTM_v0_2_Layer
-        out = G.deep_prj_lstm_dln_model_v2(None, None, 11, 13, 128, 64, 16, 2, num_conds=1, grad_clipping=1.0,
+        out = G.deep_prj_lstm_dln_model_v2(None, None, 11, 13, 128, 64, 16, 2, num_conds=1, grad_clipping=1.0, dropout=0.0,
                                            device=_dev(), seed=86)
         net = out[0] if isinstance(out, (tuple, list)) else out
     else:
@@ -318,6 +318,54 @@ def test_ln_backward_2d_decomposition_n128(kind):
     perturb_params(net, 83, 0.03)
     b = make_batch(np.random.default_rng(84), 18, 23, 11, 13, I=7 if cond_key else 0)
     run_case(net, b, cond_key=cond_key, calibrate=True)
+
+
+def test_dropout_training_matches_oracle_with_the_same_masks():
+    """models/gating_hyper_nets.py:276-307 at the reference default dropout=0.2: training (deterministic=False)
+    drops the input of every layer and of the output layer; the oracle is fed the masks the HIP path used
+    (regenerated from the Philox stream ids) and every gradient agrees at 1e-4; predict / ff ignore dropout.
+    (64-unit layers: on 8-unit toy nets a dropped 5-dim input leaves near-degenerate layer-norm rows whose
+    fp32 noise alone exceeds 1e-4.)"""
+    from asr_amd import gating_hyper_nets as G
+    D, C = 23, 17
+    for which in ('ln', 'icond'):
+        if which == 'ln':
+            net = G.deep_projection_ln_lstm_model(None, None, D, C, 2, 32, 64, grad_clipping=1.0, device=_dev(), seed=91)
+            ck = None
+        else:
+            net, _ = G.deep_projection_ivector_ln_model(None, None, None, D, C, 2, 1, 8, 64, 1.0, cond_dim=7,
+                                                        device=_dev(), seed=92)
+            ck = 'ivec'
+        assert net.dropout == 0.2                                  # the reference's default argument
+        vals = perturb_params(net, 93, 0.03)
+        b = make_batch(np.random.default_rng(94), 6, 12, D, C, I=7 if ck else 0)
+        x, m, y = (torch.from_numpy(b[k]).cuda() for k in ('x', 'mask', 'y'))
+        c = torch.from_numpy(b[ck]).cuda() if ck else None
+        onet = O.OracleNetwork(net.describe(), vals)
+        B, T = b['mask'].shape
+        for rep in range(3):                                       # a fresh mask every step
+            ce, _, _ = net.loss(x, m, y, m, c, train=True)
+            net.backward(); net.check_status()
+            masks = [mk.cpu().numpy().reshape(T, B, -1).transpose(1, 0, 2) for mk in net.dropout_masks()]
+            assert len(masks) == 3 and all(0.7 < (mk > 0).mean() < 0.9 for mk in masks)
+            if rep:
+                assert not np.array_equal(masks[1], first[1])
+            first = masks
+            for l, mk in enumerate(masks):                         # = the oracle's own Philox restatement
+                sid = (net.dropout_step << 20) | l
+                want = O.dropout_mask(T * B, mk.shape[2], 0.2, net.dropout_seed, sid)
+                assert np.array_equal(mk, want.reshape(T, B, -1).transpose(1, 0, 2))
+            _, os_, _, og = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], b.get(ck), drop=masks)
+            assert abs(ce.item() - os_) < 2e-5 * abs(os_)
+            gmax = max(np.abs(g).max() for g in og)
+            for (n, _), g, o in zip(net.param_names_shapes(), net.get_all_grad_values(), og):
+                assert np.abs(g - o).max() <= 1e-4 * (np.abs(o).max() + 1e-3 * gmax), (which, rep, n)
+        post = net.posteriors(x, m, c).cpu().numpy()               # deterministic=True: identity
+        valid = b['mask'][:, :, None] > 0
+        assert relerr(post * valid, onet.posteriors(b['x'], b['mask'], b.get(ck)) * valid) < 2e-5
+        ce_eval, _, _ = net.loss(x, m, y, m, c, train=False)
+        _, os_det, _, _ = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], b.get(ck))
+        assert abs(ce_eval.item() - os_det) < 2e-5 * abs(os_det)
 
 
 def test_projection_hyper_aux_costs_and_trainer():

@@ -441,6 +441,40 @@ def test_transformers():
     assert o.shape == (1, 7, 2) and (o[0, 3] == o[0, 5]).all() and (o[0, 6] == [4, 5]).all()
 
 
+def test_reference_held_skip_frame_vectors():
+    """The only fixtures the reference's tests hold for anything built here (test/test_libs_utils.py:22-51),
+    kept as data in tests/golden/ref_test_libs_utils.json.  testSkipFamesFixed lists one answer per start
+    offset 0, 1, 2, but the reference's current skip_frames_fixed (libs/utils.py:231-259) yields ONE
+    sub-sequence (offset 0 with return_first, else a random offset); we follow the current function and
+    reproduce each listed answer by pinning the offset."""
+    import json
+    import random
+    from asr_amd import transformers as TR
+    g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'ref_test_libs_utils.json')))
+    a_seq = np.array(g['a_seq']); n = g['every_n']
+    got = TR.skip_frames(a_seq, n, False)
+    assert np.array_equal(got[0][0], np.array(g['skip_frames']))
+    fx = list(TR.skip_frames_fixed(a_seq, n, return_first=True))
+    assert len(fx) == 1 and np.array_equal(fx[0][0][0], np.array(g['skip_frames_fixed_by_start'][0]))
+    real = random.randint
+    try:
+        for start, want in enumerate(g['skip_frames_fixed_by_start']):
+            random.randint = lambda a, b, s=start: s
+            fx = list(TR.skip_frames_fixed(a_seq, n))
+            assert len(fx) == 1 and np.array_equal(fx[0][0][0], np.array(want)), start
+    finally:
+        random.randint = real
+    # testRepeat: the un-skipping of posteriors, bin/forward_lstm2.py:99-101
+    sk = TR.skip_frames(a_seq, n, False)[0][0]
+    orig_len = len(a_seq[0][0])
+    assert np.array_equal(np.repeat(sk, n, axis=0)[:orig_len], np.array(g['repeat_then_trim']))
+    assert np.array_equal(TR.unskip(sk[None], n, orig_len)[0], np.array(g['repeat_then_trim']))
+    # the random form draws one index per block of every_n frames, clipped to the last frame
+    random.seed(3)
+    r = TR.skip_frames(a_seq, n, True)[0][0]
+    assert r.shape == (2, 2) and all(any((row == f).all() for f in a_seq[0][0][i * n:(i + 1) * n]) for i, row in enumerate(r))
+
+
 def test_regularizable_ranges_cover_the_rec_family():
     """Every gating_hyper_nets builder maps lasagne's `regularizable` tag onto whole engine tensors."""
     from asr_amd import gating_hyper_nets as G
