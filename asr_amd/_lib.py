@@ -33,7 +33,7 @@ class HyperDir(C.Structure):
                 ('cvec', fp), ('r_out', fp), ('ld_r', i32), ('hh_out', fp),
                 ('gates', fp), ('cst', fp), ('hgates', fp), ('hcst', fp), ('aD', fp),
                 ('dr_ext', fp), ('ld_dr', i32), ('dXp', fp), ('dXh', fp), ('dA', fp), ('dD', fp),
-                ('dcv', fp), ('dbh', fp)]
+                ('dcv', fp), ('dbh', fp), ('carry', fp)]
 
 
 class PrjHyperDir(C.Structure):
@@ -50,8 +50,8 @@ class PrjHyperDesc(C.Structure):
 
 
 class HyperScanDesc(C.Structure):
-    _fields_ = [('T', i32), ('B', i32), ('N', i32), ('H', i32), ('ndir', i32), ('grad_clip', f32),
-                ('clip_outcell', i32), ('lhuc_reparam', i32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
+    _fields_ = [('T', i32), ('B', i32), ('N', i32), ('H', i32), ('ndir', i32), ('step0', i32), ('step1', i32),
+                ('grad_clip', f32), ('clip_outcell', i32), ('lhuc_reparam', i32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
                 ('dir', HyperDir * 2)]
 
 

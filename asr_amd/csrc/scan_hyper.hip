@@ -34,10 +34,12 @@ struct HyperDir {
     float* dD;               // (T,B,3,4N) [dgates*a, dgates*xproj, dgates] -> dM, dcvec
     float* dcv;              // (ceil(B/8),12N) or null: column sums of dD over time and batch, per batch chunk
     float* dbh;              // (ceil(B/8),4H)  or null: column sums of dXh
+    float* carry;            // (B, 2N+2H) or null: BPTT state handed from one time chunk's launch to the next
 };
 
 struct HyperArgs {
     int T, B, N, H, G, UH, KS, KSP, KT, HS, HSP, HT;
+    int s0, s1;                  // steps [s0, s1) of the T-step recurrence run by this launch (in processing order)
     int R, MT, KQ, NBLK, NBW;    // backward W_h product: see hyper_dims
     int ndir, chunk0, rpc;       // rpc = batch rows per chunk/group (8 or 16)
     float clip;
@@ -246,12 +248,32 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         cv_x = *(const f32x4*)(D.cvec + 4 * N + col4);
         cv_b = *(const f32x4*)(D.cvec + 8 * N + col4);
     }
+    const int s0 = A.s0, s1 = A.s1;
     // zero both parities of both exchange buffers, padding included (state 0 at step 0; padded blocks
     // meet zero weights, but 0 x stale NaN would still poison the MFMA): the group's G workgroups
     // share the work; the first wait below orders it before any reader and any later writer
     for (int i = j * 256 + tid; i < 2 * KSP * 16; i += G * 256) st_sc1_f4(rex_rs, (unsigned)i * 16u, f32x4{0, 0, 0, 0});
     for (int i = j * 256 + tid; i < 2 * HSP * 16; i += G * 256) st_sc1_f4(hex_rs, (unsigned)i * 16u, f32x4{0, 0, 0, 0});
     group_publish(gs);
+    if (s0 > 0) {
+        // a later time chunk: the carried state is what the previous launch saved for step s0 - 1 (the
+        // saved rows hold the masked, i.e. carried, values); every workgroup re-publishes its part of
+        // h_{s0-1}, hhat_{s0-1} into the parity step s0 reads, behind the zeroing above
+        if (!group_wait(gs)) return;
+        const int tp = D.reverse ? T - s0 : s0 - 1;
+        const size_t rowp = (size_t)tp * B + b;
+        const int par0 = s0 & 1;
+        if (wave == 0) {
+            if (bvalid) { c = D.cst[rowp * N + unit]; r = D.r_out[rowp * D.ld_r + unit]; }
+            const float r1 = __shfl(r, bl + 16), r2 = __shfl(r, bl + 32), r3 = __shfl(r, bl + 48);
+            if (q == 0) st_sc1_f4(rex_rs, (unsigned)((((size_t)par0 * KSP + j) * 64 + bl * 4) * 4), f32x4{r, r1, r2, r3});
+        }
+        if (wave == 1 && hvalid) {
+            if (bvalid) { hc = D.hcst[rowp * H + hu]; hh = D.hh_out[rowp * H + hu]; }
+            st_sc1(hex + ((size_t)par0 * HSP * 64) + ((size_t)(hu >> 2) * 16 + bl) * 4 + (hu & 3), hh);
+        }
+        group_publish(gs);
+    }
 
     const int ks4 = KSP / 16, hs4 = HSP / 16;    // b128 groups per wave
     // inputs of the step, loaded one step ahead through walking per-lane pointers; branch-free (every
@@ -260,22 +282,23 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
     const int bq = bvalid ? b : (B - 1), huq = hvalid ? hu : 0;
     const float* const dummy = D.wpack;
     const int dt = D.reverse ? -1 : 1;
-    const size_t r00 = (size_t)(D.reverse ? T - 1 : 0) * B + bq;
-    const float* p_m = (w0 || w1) ? A.mask + (size_t)(D.reverse ? T - 1 : 0) * A.mst + (size_t)bq * A.msb : dummy;
+    const int t00 = D.reverse ? T - 1 - s0 : s0;              // time index of the first step of this launch
+    const size_t r00 = (size_t)t00 * B + bq;
+    const float* p_m = (w0 || w1) ? A.mask + (size_t)t00 * A.mst + (size_t)bq * A.msb : dummy;
     const float* p_x = w0 ? D.xproj + r00 * 4 * N + col4 : dummy;
     const float* p_xh = w1 ? D.xhproj + r00 * 4 * H + huq * 4 : dummy;
     const int s_m = (w0 || w1) ? dt * A.mst : 0, s_x = w0 ? dt * B * 4 * N : 0, s_xh = w1 ? dt * B * 4 * H : 0;
     float n_m = *p_m;
     f32x4 n_x4 = *(const f32x4*)p_x, n_xh4 = *(const f32x4*)p_xh;
     STAMP_DECL
-    for (int step = 0; step < T; ++step) {
+    for (int step = s0; step < s1; ++step) {
         const int t = D.reverse ? T - 1 - step : step;
         const int par = step & 1;
         const size_t row = (size_t)t * B + b;
         const float m = bvalid ? n_m : 0.f;
         const f32x4 x4 = n_x4, xh4 = n_xh4;
         {
-            const bool go = step + 1 < T;
+            const bool go = step + 1 < s1;
             p_m += go ? s_m : 0; p_x += go ? s_x : 0; p_xh += go ? s_xh : 0;
             n_m = *p_m; n_x4 = *(const f32x4*)p_x; n_xh4 = *(const f32x4*)p_xh;
         }
@@ -522,6 +545,19 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     float dhc = 0.f, dhh_pass = 0.f, dhh_rec = 0.f;     // wave 1 lanes
     // running column sums (d cvec, d bhat): formed here for free instead of re-reading dD / dXh
     f32x4 cs_h = {0, 0, 0, 0}, cs_x = {0, 0, 0, 0}, cs_g = {0, 0, 0, 0}, cs_hg = {0, 0, 0, 0};
+    const int s0 = A.s0, s1 = A.s1;
+    if (s0 > 0) {
+        // a later time chunk of the BPTT: the gradient state and the running column sums continue from
+        // where the previous launch (steps < s0) left them
+        const float* cy = D.carry + (size_t)(bvalid ? b : 0) * (2 * N + 2 * H);
+        if (wave == 0 && bvalid) { dc = cy[unit]; dh_in = cy[N + unit]; }
+        if (wave == 1 && bvalid && hvalid) { dhc = cy[2 * N + hu]; dhh_rec = cy[2 * N + H + hu]; }
+        if (D.dcv && wave == 0 && bl == 0) {
+            const float* o_ = D.dcv + (size_t)chunk * 12 * N;
+            cs_h = *(const f32x4*)(o_ + col4); cs_x = *(const f32x4*)(o_ + 4 * N + col4); cs_g = *(const f32x4*)(o_ + 8 * N + col4);
+        }
+        if (D.dbh && wave == 1 && bl == 0 && hvalid) cs_hg = *(const f32x4*)(D.dbh + (size_t)chunk * 4 * H + hu * 4);
+    }
     __syncthreads();
 
     // saved tensors of the step about to be processed, prefetched one step ahead
@@ -543,9 +579,10 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     // per-lane stride; 0 for the lanes that read the dummy line): the in-loop prefetch is a dozen loads
     // and pointer adds, with no kernel-argument reloads or 64-bit multiplies on the step's critical path
     const int dt = D.reverse ? 1 : -1;
-    const size_t r00 = (size_t)(D.reverse ? 0 : T - 1) * B + bq;          // row of the first step
+    const int t00 = D.reverse ? s0 : T - 1 - s0;                          // time index of this launch's first step
+    const size_t r00 = (size_t)t00 * B + bq;                              // its row
     const bool w01 = w0 || w1;
-    const float* p_m = w01 ? A.mask + (size_t)(D.reverse ? 0 : T - 1) * A.mst + (size_t)bq * A.msb : dummy;
+    const float* p_m = w01 ? A.mask + (size_t)t00 * A.mst + (size_t)bq * A.msb : dummy;
     const float* p_g = w0 ? D.gates + r00 * 4 * N + col4 : dummy;
     const float* p_x = w0 ? D.xproj + r00 * 4 * N + col4 : dummy;
     const float* p_a = w0 ? D.aD + r00 * 12 * N + col4 : dummy;
@@ -561,10 +598,10 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     // flight); a second load of the same row behind a select made hipcc merge the two loads' results at
     // a join, i.e. wait for the fresh load (see above).
     auto row_of = [&](int k) { k = k < T ? k : T - 1; return (size_t)(D.reverse ? k : T - 1 - k) * B + bq; };
-    const float* p_c2 = w0 ? D.cst + row_of(2) * N + unit : dummy;
-    const float* p_hc2 = w1 ? D.hcst + row_of(2) * H + huq : dummy;
-    float c0 = *(w0 ? D.cst + row_of(0) * N + unit : dummy), c1 = *(w0 ? D.cst + row_of(1) * N + unit : dummy);
-    float hc0 = *(w1 ? D.hcst + row_of(0) * H + huq : dummy), hc1 = *(w1 ? D.hcst + row_of(1) * H + huq : dummy);
+    const float* p_c2 = w0 ? D.cst + row_of(s0 + 2) * N + unit : dummy;
+    const float* p_hc2 = w1 ? D.hcst + row_of(s0 + 2) * H + huq : dummy;
+    float c0 = *(w0 ? D.cst + row_of(s0) * N + unit : dummy), c1 = *(w0 ? D.cst + row_of(s0 + 1) * N + unit : dummy);
+    float hc0 = *(w1 ? D.hcst + row_of(s0) * H + huq : dummy), hc1 = *(w1 ? D.hcst + row_of(s0 + 1) * H + huq : dummy);
     float n_c2 = 0.f, n_hc2 = 0.f;
     // loads the step the pointers stand on
     auto prefetch = [&]() {
@@ -585,7 +622,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
     };
     prefetch();
     STAMP_DECL
-    for (int step = 0; step < T; ++step) {
+    for (int step = s0; step < s1; ++step) {
         const int st = T - 1 - step;
         const int t = D.reverse ? T - 1 - st : st;
         const int par = step & 1;
@@ -830,6 +867,11 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         STAMP(8);
         __syncthreads();
     }
+    if (s1 < T && D.carry && bvalid) {                  // hand the BPTT state to the next time chunk's launch
+        float* cy = D.carry + (size_t)b * (2 * N + 2 * H);
+        if (wave == 0) { cy[unit] = dc; cy[N + unit] = dh_pass + dh_in; }
+        if (wave == 1 && hvalid) { cy[2 * N + hu] = dhc; cy[2 * N + H + hu] = dhh_pass + dhh_rec; }
+    }
     if (D.dcv && wave == 0) {                           // sum over the 16 batch lanes, lane bl == 0 writes
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
@@ -857,6 +899,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
 // ------------------------------------------------------------------------------------------------
 struct asr_hyper_scan_desc {
     int T, B, N, H, ndir;
+    int step0, step1;            // steps [step0, step1) of the recurrence, in processing order; step1 == 0: all T
     float grad_clip;
     int clip_outcell;
     int lhuc_reparam;            // 0: HyperLSTM / scaling; 1 relu, 2 exp, 3 identity, 4 2sigmoid: HyperLHUCLSTMLayer
@@ -898,6 +941,13 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     }
     if (ws_bytes < asr_hyper_scan_ws_bytes(d->T, d->B, d->N, d->H, d->ndir, backward)) return ASR_ERR_WS;
     if (d->T == 0) return ASR_OK;
+    A.s0 = d->step0; A.s1 = d->step1 > 0 ? d->step1 : d->T;
+    if (A.s0 < 0 || A.s0 >= A.s1 || A.s1 > d->T) return ASR_ERR_ARG;
+    for (int k = 0; k < d->ndir; ++k) {                  // a time chunk other than the first continues saved state
+        const HyperDir& D = d->dir[k];
+        if (!backward && A.s0 > 0 && (!D.cst || !D.hcst)) return ASR_ERR_ARG;
+        if (backward && (A.s0 > 0 || A.s1 < d->T) && !D.carry) return ASR_ERR_ARG;
+    }
     if (A.G * d->ndir > 256) return ASR_ERR_ARG;         // co-residency bound of the persistent grid
     A.T = d->T; A.B = d->B; A.ndir = d->ndir; A.clip = d->grad_clip;
     A.clip_out = d->clip_outcell ? d->grad_clip : 0.f;

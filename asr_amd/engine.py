@@ -637,6 +637,12 @@ class Network(object):
         # DropoutLayer(p) in front of every layer and of the output layer (models/gating_hyper_nets.py:276-307);
         # active when train=True (deterministic=False).  The mask is a pure function of (dropout_seed,
         # step, rank, layer): the backward pass regenerates it, nothing is stored.
+        # time chunks per layer of the scans that support it (engine_hyper.HyperPair): the next layer's input
+        # projection / this layer's dX run on the side stream under the remaining chunks.  Measured on cfg3
+        # (DESIGN.md section 4): 1 / 2 / 4 / 8 chunks = 185.5 / 185.4 / 185.0 / 185.9 ms per step -- the GEMMs
+        # that leave the critical path slow the latency-bound scans by as much as they save, so 1 is the default
+        self.scan_chunks = int(os.environ.get('ASR_SCAN_CHUNKS', '1'))
+        self.input_ready = False     # the output layer as a consumer of piecewise input (accumulate_input)
         self.dropout = 0.0
         self.dropout_seed = 0
         self.dropout_rank = 0
@@ -813,7 +819,8 @@ class Network(object):
         e0.record()
         r = call()
         e1.record()
-        self.scan_events.append((kind, bool(backward), desc.T * desc.B, desc.ndir, e0, e1))
+        steps = (getattr(desc, 'step1', 0) or desc.T) - getattr(desc, 'step0', 0)
+        self.scan_events.append((kind, bool(backward), steps * desc.B, desc.ndir, e0, e1))
         return r
 
     def scan_lstm(self, pair, desc, backward):
@@ -874,14 +881,30 @@ class Network(object):
         for l, pair in enumerate(self.pairs):
             if drop:
                 act = self._dropout_fwd(l, act)
-            act = pair.forward(act, T, B, mask, cond, train)
+            nxt = self.pairs[l + 1] if l + 1 < len(self.pairs) else self
+            if self.overlap and not drop and hasattr(pair, 'chunked_forward') and hasattr(nxt, 'accumulate_input'):
+                act = pair.forward(act, T, B, mask, cond, train, consumer=nxt)
+            else:
+                act = pair.forward(act, T, B, mask, cond, train)
         if drop:
             act = self._dropout_fwd(len(self.pairs), act)
         self.top = act
         logits = self.arena.mat('logits', T * B, self.C)
-        ops.gemm(act, self.out.p('W'), logits, bias=self.out.p('b'))   # libs/builder_utils.py:44-45
+        if self.input_ready:                     # already projected piecewise under the top layer's scan
+            self.input_ready = False
+        else:
+            ops.gemm(act, self.out.p('W'), logits, bias=self.out.p('b'))   # libs/builder_utils.py:44-45
         self.logits = logits
         return logits
+
+    # the output layer as the consumer of a chunked top layer (same protocol as HyperPair.begin_input)
+    def begin_input(self, T, B):
+        self._logits_in = self.arena.mat('logits', T * B, self.C)
+        self.input_ready = True
+
+    def accumulate_input(self, Xpart, r0, r1, k0, first):
+        ops.gemm(Xpart, self.out.p('W')[k0:k0 + Xpart.shape[1]], self._logits_in[r0:r1], beta=0.0 if first else 1.0,
+                 bias=self.out.p('b') if first else None)
 
     def _dropout_fwd(self, l, X):
         sid = (self.dropout_step << 20) | ((self.dropout_rank & 0xfff) << 8) | l

@@ -38,11 +38,28 @@ def perm4(src, dst, rows, N, inverse=False):
     return dst
 
 
+def chunk_bounds(T, n):
+    """Time-chunk boundaries 0 = b_0 < ... < b_n = T, symmetric (b_i + b_{n-i} = T): the launch that runs
+    steps [b_k, b_k+1) covers time chunk k of the forward direction and time chunk n-1-k of the reverse
+    direction, both on the same grid."""
+    n = max(1, min(int(n), T))
+    b = [0] * (n + 1)
+    for i in range(n + 1):
+        b[i] = (i * T) // n if 2 * i <= n else T - ((n - i) * T) // n
+    return [v for k, v in enumerate(b) if k == 0 or v > b[k - 1]]
+
+
 class HyperPair(object):
+    """Runs as `net.scan_chunks` consecutive launches over time chunks when training at T >= 256 (steps
+    [step0, step1) of asr_hyper_scan_desc): the half of the NEXT layer's input projection (or of the output
+    layer) that a finished chunk already determines runs on the side stream under the following chunks, and
+    backward the same holds for dX; only the last chunk's share of those GEMMs stays on the critical path."""
     kind = 'hyper'
     stateful = False
     lhuc = 0                     # asr_hyper_scan_desc.lhuc_reparam
     _mk = staticmethod(_mk_hyper)
+    input_ready = False
+    chunked_forward = True
 
     def __init__(self, net, idx, D, N, H, Z, clip, ndir):
         self.net = net; self.idx = idx
@@ -84,7 +101,29 @@ class HyperPair(object):
         perm4(Mg, Mi, (H + 1) * 3, N)
         return Mi
 
-    def forward(self, X, T, B, mask, cond, train):
+    # ---- consumer side: the input projection arrives in pieces from the layer below
+    def begin_input(self, T, B):
+        rows = T * B
+        self._in = [(self._buf('xproj%d' % d, rows, 4 * self.N), self._buf('xhproj%d' % d, rows, 4 * self.H))
+                    for d in range(self.ndir)]
+        self.input_ready = True
+
+    def accumulate_input(self, Xpart, r0, r1, k0, first):
+        """rows [r0, r1) of xproj / xhproj (+)= Xpart . W[k0 : k0 + Xpart.shape[1]]  (bias with the first piece)"""
+        N = self.N
+        kw = Xpart.shape[1]
+        for d, dp in enumerate(self.dirs):
+            xp, xh = self._in[d]
+            ops.gemm(Xpart, dp.p('Wx')[k0:k0 + kw], xp[r0:r1], beta=0.0 if first else 1.0,
+                     bias=self._xbias(dp) if first else None)
+            ops.gemm(Xpart, dp.p('Wxh')[N + k0:N + k0 + kw], xh[r0:r1], beta=0.0 if first else 1.0,
+                     bias=dp.p('bh') if first else None)
+
+    def _bounds(self, T, train):
+        n = self.net.scan_chunks if (train and T >= 256) else 1
+        return chunk_bounds(T, n)
+
+    def forward(self, X, T, B, mask, cond, train, consumer=None):
         net = self.net; N, H = self.N, self.H
         rows = T * B
         L = _lib.lib()
@@ -93,11 +132,16 @@ class HyperPair(object):
         desc.T, desc.B, desc.N, desc.H, desc.ndir = T, B, N, H, self.ndir
         desc.grad_clip = self.clip; desc.lhuc_reparam = self.lhuc
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
-        self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[])
+        self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[], train=train)
+        fed = self.input_ready
+        self.input_ready = False
         for d, dp in enumerate(self.dirs):
             c = {}
-            c['xproj'] = ops.gemm(X, dp.p('Wx'), self._buf('xproj%d' % d, rows, 4 * N), bias=self._xbias(dp))
-            c['xhproj'] = ops.gemm(X, dp.p('Wxh')[N:], self._buf('xhproj%d' % d, rows, 4 * H), bias=dp.p('bh'))
+            if fed:                              # projected piecewise by the layer below (accumulate_input)
+                c['xproj'], c['xhproj'] = self._in[d]
+            else:
+                c['xproj'] = ops.gemm(X, dp.p('Wx'), self._buf('xproj%d' % d, rows, 4 * N), bias=self._xbias(dp))
+                c['xhproj'] = ops.gemm(X, dp.p('Wxh')[N:], self._buf('xhproj%d' % d, rows, 4 * H), bias=dp.p('bh'))
             Mi = self._fold(dp, d)
             c['Mi'] = Mi
             for mode, nm in ((0, 'wpk'), (1, 'wpkb')):
@@ -124,7 +168,26 @@ class HyperPair(object):
                 c['hcst'] = self._buf('hcst%d' % d, rows, H); Dd.hcst = c['hcst'].data_ptr()
                 c['aD'] = self._buf('aD%d' % d, rows, 12 * N); Dd.aD = c['aD'].data_ptr()
             ctx['d'].append(c)
-        net.scan_hyper(self, desc, backward=False)
+        bnd = self._bounds(T, train)
+        n = len(bnd) - 1
+        pipe = consumer is not None and n > 1
+        if pipe:
+            consumer.begin_input(T, B)
+        for k in range(n):
+            desc.step0, desc.step1 = bnd[k], bnd[k + 1]
+            net.scan_hyper(self, desc, backward=False)
+            if pipe:
+                with net.deferred():
+                    # forward direction finished time chunk k, reverse direction time chunk n-1-k; a time chunk's
+                    # first piece is the one of the earlier launch (same launch: the forward direction's)
+                    consumer.accumulate_input(Y[bnd[k] * B:bnd[k + 1] * B, 0:N], bnd[k] * B, bnd[k + 1] * B, 0,
+                                              first=(self.ndir == 1 or 2 * k <= n - 1))
+                    if self.ndir == 2:
+                        j = n - 1 - k
+                        consumer.accumulate_input(Y[bnd[j] * B:bnd[j + 1] * B, N:2 * N], bnd[j] * B, bnd[j + 1] * B, N,
+                                                  first=(2 * k < n - 1))
+        if pipe:
+            net.join_deferred()
         return Y
 
     def backward(self, dY, need_dx=True):
@@ -151,10 +214,33 @@ class HyperPair(object):
             nsl = (B + 7) // 8                         # per batch chunk; unused slots stay zero
             c['dcv'] = self._buf('dcv%d' % d, nsl, 12 * N); c['dcv'].zero_(); Dd.dcv = c['dcv'].data_ptr()
             c['dbh'] = self._buf('dbh%d' % d, nsl, 4 * H); c['dbh'].zero_(); Dd.dbh = c['dbh'].data_ptr()
-        net.scan_hyper(self, desc, backward=True)
-        # critical path first: dX feeds the BPTT scan of the layer below
+            Dd.carry = self._buf('carry%d' % d, B, 2 * N + 2 * H).data_ptr()
+        bnd = self._bounds(T, ctx.get('train', True))
+        n = len(bnd) - 1
         dX = self._buf('dX', rows, self.D) if need_dx else None
-        if need_dx:
+
+        def dx_piece(d, j, first):
+            """dX rows of time chunk j (+)= this direction's share: critical path (feeds the scan below)"""
+            r0, r1 = bnd[j] * B, bnd[j + 1] * B
+            dp = self.dirs[d]; c = ctx['d'][d]
+            ops.gemm(c['dXp'][r0:r1], dp.p('Wx'), dX[r0:r1], tb=True, beta=0.0 if first else 1.0)
+            ops.gemm(c['dXh'][r0:r1], dp.p('Wxh')[N:], dX[r0:r1], tb=True, beta=1.0)
+
+        for k in range(n):
+            desc.step0, desc.step1 = bnd[k], bnd[k + 1]
+            net.scan_hyper(self, desc, backward=True)
+            if need_dx and n > 1:
+                # BPTT steps [b_k, b_k+1): the reverse direction has finished time chunk k, the forward direction
+                # time chunk n-1-k; their dX shares run on the side stream under the next chunks
+                with net.deferred():
+                    if self.ndir == 2:
+                        dx_piece(1, k, first=(2 * k <= n - 1))
+                        dx_piece(0, n - 1 - k, first=(2 * k < n - 1))
+                    else:
+                        dx_piece(0, n - 1 - k, first=True)
+        if need_dx and n > 1:
+            net.join_deferred()
+        elif need_dx:
             for d, dp in enumerate(self.dirs):
                 c = ctx['d'][d]
                 ops.gemm(c['dXp'], dp.p('Wx'), dX, tb=True, beta=0.0 if d == 0 else 1.0)

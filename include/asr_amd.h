@@ -206,10 +206,18 @@ typedef struct asr_hyper_dir {
     float* dD;                /* (T,B,3,4N) [dgates*a, dgates*xproj, dgates] -> dM, dcvec */
     float* dcv;               /* (ceil(B/8),12N) or NULL: column sums of dD (d cvec) per 16-row batch chunk */
     float* dbh;               /* (ceil(B/8),4H) or NULL: column sums of dXh (d bhat) per batch chunk */
+    float* carry;             /* (B, 2N+2H) BPTT state handed from one time chunk's launch to the next (backward with
+                               * step0 > 0 or step1 < T), else NULL */
 } asr_hyper_dir;
 
 typedef struct asr_hyper_scan_desc {
     int T, B, N, H, ndir;
+    int step0, step1;         /* run steps [step0, step1) of the T-step recurrence (processing order: the reverse
+                               * direction's step s is time T-1-s; the BPTT's step s is the forward's step T-1-s);
+                               * step1 == 0 means T.  A layer may be run as consecutive time chunks, one launch each:
+                               * the forward continues from the rows it saved for step0-1 (training mode: gates/cst/
+                               * hgates/hcst given), the backward from `carry`; dcv / dbh accumulate across chunks.  The
+                               * caller can then run the next layer's input projection on finished chunks meanwhile. */
     float grad_clip;
     int clip_outcell;         /* 1: also grad_clip the outcell of both cells (ScalingHyperLSTMLayer,
                                * libs/lasagne_libs/hyper_layers.py:1016-1022,1083-1089) */

@@ -203,6 +203,43 @@ def test_hyperlstm_small(is_bidir, clip):
     run_case(net, b)
 
 
+@pytest.mark.parametrize('chunks,is_bidir,lhuc', [(4, True, False), (3, True, False), (5, False, False), (4, True, True)])
+def test_hyper_time_chunked_launches_match_one_launch(chunks, is_bidir, lhuc):
+    """A layer run as consecutive time chunks (asr_hyper_scan_desc.step0/step1; state continued from the saved
+    rows forward, from `carry` backward; the next layer's projection, the output layer and dX pipelined piecewise
+    on the side stream) gives what the single launch gives: recurrence outputs bit for bit, everything that
+    passes through the re-associated GEMM sums to fp32 rounding; and both match the oracle.  B = 18: two batch
+    chunks; ragged lengths, one row of length 1."""
+    from asr_amd.builders import build_deep_hyperlstm, build_deep_hyperlhuclstm
+    def build():
+        if lhuc:
+            net = build_deep_hyperlhuclstm('hyperlhuc', None, None, 11, 2, 32, 8, 4, 13, 1.0, is_bidir, 0,
+                                           device=_dev(), seed=8)
+        else:
+            net = build_deep_hyperlstm('hyper', None, None, 11, 2, 32, 8, 4, 13, 1.0, is_bidir, 0, device=_dev(), seed=8)
+        perturb_params(net, 17, 0.03)
+        return net
+    b = make_batch(np.random.default_rng(19), 18, 300, 11, 13)
+    x, m, y = (torch.from_numpy(b[k]).cuda() for k in ('x', 'mask', 'y'))
+    res = []
+    for n in (1, chunks):
+        net = build()
+        net.scan_chunks = n
+        ce, _, pred = net.loss(x, m, y, m)
+        net.backward(); net.check_status()
+        res.append((ce.item(), pred.cpu().numpy(), [p.ctx['Y'].clone() for p in net.pairs], net.store.g.clone(), net))
+    (ce1, pr1, y1, g1, _), (ce2, pr2, y2, g2, net) = res
+    assert torch.equal(y1[0], y2[0])                       # first layer: same projections, same recurrence
+    assert (y1[1] - y2[1]).abs().max().item() < 1e-5 and abs(ce1 - ce2) < 1e-5 * abs(ce1)
+    assert ((g1 - g2).abs().max() / g1.abs().max()).item() < 2e-5
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    _, os_, _, og = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    assert abs(ce2 - os_) < 2e-5 * abs(os_)
+    gmax = max(np.abs(g).max() for g in og)
+    for (nm, _), g, o in zip(net.param_names_shapes(), net.get_all_grad_values(), og):
+        assert np.abs(g - o).max() <= 1e-4 * (np.abs(o).max() + 1e-3 * gmax), nm
+
+
 def test_hyperlstm_medium():
     """N=64, H=16, Z=8: 16 workgroups per direction, 1 hyper unit per workgroup, B=18 > 16."""
     from asr_amd.builders import build_deep_hyperlstm
