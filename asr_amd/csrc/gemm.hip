@@ -12,6 +12,13 @@
 #define BK 16
 #define LDSP 132   // padded row (floats): 128 + 4 keeps 16-B alignment and breaks bank aliasing
 
+// Optional bf16 mode (BASELINE.json north_star: "a stated bound in the optional bf16 mode"): the same kernel
+// with BF = true rounds both operands to bf16 (round to nearest even, v_cvt_pk_bf16_f32) while staging them
+// into LDS and multiplies with v_mfma_f32_32x32x16_bf16, fp32 accumulate; HBM tensors stay fp32.  LDS image
+// [k / 8][row][k % 8]: a lane's 8 consecutive k of its row are one conflict-free ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
 // element (r,c) of op(X): X stored row-major with leading dim ld; if TR, op(X)[r][c] = X[c][r]
 template <bool TR>
 __device__ __forceinline__ float ldg_op(const float* X, int ld, int r, int c, int R, int C) {
@@ -19,7 +26,7 @@ __device__ __forceinline__ float ldg_op(const float* X, int ld, int r, int c, in
     return TR ? X[(size_t)c * ld + r] : X[(size_t)r * ld + c];
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool BF>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, float alpha,
                                                         const float* __restrict__ A, int lda,
                                                         const float* __restrict__ B, int ldb,
@@ -28,6 +35,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
                                                         int kchunk, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDSP];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDSP];
+    __bf16 (*Ah)[2][BM][8] = (__bf16 (*)[2][BM][8])&As[0][0][0];      // bf16 images in the same storage
+    __bf16 (*Bh)[2][BN][8] = (__bf16 (*)[2][BN][8])&Bs[0][0][0];
 
     // XCD-aware tile order: blocks b and b+8 share an L2; give each XCD a contiguous strip of
     // tiles along N so the A row-panel is re-used from that L2.
@@ -91,6 +100,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         }
     };
     auto store_tiles = [&](int buf) {
+        if (BF) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid;
+                if (TA) {                                   // 4 consecutive rows of one k
+                    const int k = idx / 32, m4 = (idx % 32) * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Ah[buf][k >> 3][m4 + i][k & 7] = (__bf16)ra[e][i];
+                } else {                                    // 4 consecutive k of one row: one 8-byte store
+                    const int m = idx / 4, k4 = (idx % 4) * 4;
+                    *(bf16x4*)&Ah[buf][k4 >> 3][m][k4 & 7] = bf16x4{(__bf16)ra[e][0], (__bf16)ra[e][1], (__bf16)ra[e][2], (__bf16)ra[e][3]};
+                }
+                if (TB) {
+                    const int n = idx / 4, k4 = (idx % 4) * 4;
+                    *(bf16x4*)&Bh[buf][k4 >> 3][n][k4 & 7] = bf16x4{(__bf16)rb[e][0], (__bf16)rb[e][1], (__bf16)rb[e][2], (__bf16)rb[e][3]};
+                } else {
+                    const int k = idx / 32, n4 = (idx % 32) * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Bh[buf][k >> 3][n4 + i][k & 7] = (__bf16)rb[e][i];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = e * 256 + tid;
@@ -115,6 +147,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int lr = lane & 31, lk = lane >> 5;
     auto mfma_tile = [&](int buf) {
+        if (BF) {                                // K = 16 per instruction: lane half lk holds k = 8 lk .. 8 lk + 7
+            const bf16x8 a0 = *(const bf16x8*)&Ah[buf][lk][wm * 64 + lr][0], a1 = *(const bf16x8*)&Ah[buf][lk][wm * 64 + 32 + lr][0];
+            const bf16x8 b0 = *(const bf16x8*)&Bh[buf][lk][wn * 64 + lr][0], b1 = *(const bf16x8*)&Bh[buf][lk][wn * 64 + 32 + lr][0];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            return;
+        }
         // all LDS operands of the tile are requested up front (32 VGPRs): LDS returns in order, so the
         // first MFMAs start after the first reads and the rest of the read latency hides under them
         float a0[BK / 2], a1[BK / 2], b0[BK / 2], b1[BK / 2];
@@ -234,9 +275,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 
 // ws (optional): scratch for split-K partials.  Split-K is used when the output has too few tiles to
 // fill the chip and K is long (the weight-gradient contractions, K = T*B).
-extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A,
-                               int lda, const float* B, int ldb, float beta, float* C, int ldc,
-                               const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
+static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                       int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                       const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (M < 0 || N < 0 || K < 0 || !C) return ASR_ERR_ARG;
     if (M == 0 || N == 0) return ASR_OK;
     if (K > 0 && (!A || !B)) return ASR_ERR_ARG;
@@ -263,9 +304,13 @@ extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, floa
     }
     float* part = ns > 1 ? ws : nullptr;
     dim3 grid(tiles, ns), block(256);
-#define LAUNCH(TA_, TB_)                                                                         \
-    hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, block, 0, stream, M, N, K, alpha, A, lda, \
-                       B, ldb, beta, C, ldc, bias, ntn, kchunk, part)
+#define LAUNCH(TA_, TB_)                                                                                \
+    do {                                                                                                \
+        if (bf16) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, M, N, K, alpha, A, \
+                                     lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);               \
+        else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, false>), grid, block, 0, stream, M, N, K, alpha, A, \
+                                lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);                    \
+    } while (0)
     if (!transA && !transB) LAUNCH(false, false);
     else if (!transA && transB) LAUNCH(false, true);
     else if (transA && !transB) LAUNCH(true, false);
@@ -280,6 +325,18 @@ extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, floa
         ASR_CHECK_LAUNCH();
     }
     return ASR_OK;
+}
+
+extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                               int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                               const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
+    return gemm_launch(false, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, stream);
+}
+// the optional bf16 mode: fp32 tensors in memory, operands rounded to bf16 on the way into LDS, fp32 accumulate
+extern "C" int asr_gemm_bf16_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                                int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                                const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
+    return gemm_launch(true, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, stream);
 }
 
 extern "C" int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A,

@@ -9,7 +9,7 @@
 //              barrier, ONE lane adds 1 to the group's monotonic arrival counter (agent scope);
 //   consumer : ONE lane polls the counter with sc1 loads until it reaches epoch*G, workgroup barrier,
 //              then EVERY load of the handed-off bytes is an sc1 load (no L1 involvement).
-// Every spin is bounded by a wall-clock deadline; on expiry the group's abort word is raised, every
+// Every wait is bounded by its own wall-clock deadline (10 s from its first unsuccessful poll); on expiry the group's abort word is raised, every
 // workgroup leaves its time loop, and the host reports ASR_ERR_TIMEOUT from asr_scan_status().
 #pragma once
 #include "common.h"
@@ -70,7 +70,9 @@ __device__ __forceinline__ void group_publish_wave(GroupSync& gs, bool storing_w
     }
 }
 
-// returns false when the group aborted (timeout somewhere): caller must leave its loop
+// returns false when the group aborted (timeout somewhere): caller must leave its loop.  The deadline bounds
+// THIS wait (armed at its first unsuccessful poll), not the launch: a long sequence, a profiler-serialised run
+// or time slicing with another process cannot trip it.
 __device__ __forceinline__ bool group_wait(GroupSync& gs) {
     gs.epoch += 1;
     if ((threadIdx.x >> 6) == (blockDim.x >> 6) - 1) {    // the LAST wave polls (it owns no per-step global
@@ -78,6 +80,7 @@ __device__ __forceinline__ bool group_wait(GroupSync& gs) {
                                                           // lane s watches shard s, lane 16 the abort word
         const unsigned target = gs.epoch * gs.members;
         int good = 1;
+        bool armed = false;
         for (;;) {
             unsigned v = 0;
             if (lane <= SYNC_SHARDS)
@@ -86,7 +89,8 @@ __device__ __forceinline__ bool group_wait(GroupSync& gs) {
             const bool aborted = (lane == SYNC_SHARDS) && v != 0;
             if (__any(aborted)) { good = 0; break; }
             if (__all(arrived)) break;
-            if (__builtin_amdgcn_s_memrealtime() > gs.deadline) {
+            if (!armed) { gs.deadline = __builtin_amdgcn_s_memrealtime() + SCAN_DEADLINE_TICKS; armed = true; }
+            else if (__builtin_amdgcn_s_memrealtime() > gs.deadline) {
                 if (lane == 0)
                     __hip_atomic_store(gs.words + SYNC_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 good = 0;
@@ -142,6 +146,22 @@ __device__ __forceinline__ float sum_q(float v) {
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- host side: can a persistent grid of `nwg` workgroups with `lds` bytes of LDS each be co-resident?
+// (fewer CUs than the full chip -- a compute partition, a CU mask, another process's persistent grid -- would
+// leave workgroups un-dispatched and every group wait would run into its deadline: refuse up front instead)
+static inline bool scan_grid_fits(size_t nwg, size_t lds) {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return false;
+        cus[dev] = n;
+    }
+    const size_t per_cu = lds > 0 ? (160 * 1024) / lds : 1;
+    return nwg <= (size_t)cus[dev] * (per_cu < 1 ? 1 : per_cu);
 }
 
 // ---- optional in-kernel phase stamps (diagnostic build only: -DSCAN_STAMPS; never in the product .so)

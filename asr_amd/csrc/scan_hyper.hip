@@ -992,13 +992,11 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
         const int nc = nchunk - c0 < cpl ? nchunk - c0 : cpl;
         A.chunk0 = c0;
         dim3 grid(A.G, d->ndir, nc), block(256);
-        if (!backward) {
-            hipFuncSetAttribute((const void*)hyper_scan_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(hyper_scan_fwd_kernel, grid, block, lds, stream, A, per_wg);
-        } else {
-            hipFuncSetAttribute((const void*)hyper_scan_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(hyper_scan_bwd_kernel, grid, block, lds, stream, A, per_wg);
-        }
+        if (!scan_grid_fits((size_t)A.G * d->ndir * nc, lds)) return ASR_ERR_ARG;
+        const void* fn = backward ? (const void*)hyper_scan_bwd_kernel : (const void*)hyper_scan_fwd_kernel;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (!backward) hipLaunchKernelGGL(hyper_scan_fwd_kernel, grid, block, lds, stream, A, per_wg);
+        else hipLaunchKernelGGL(hyper_scan_bwd_kernel, grid, block, lds, stream, A, per_wg);
         ASR_CHECK_LAUNCH();
     }
     return ASR_OK;

@@ -1301,12 +1301,15 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
         Al.nchunk = nc;
         Al.chunk0 = c0;
         dim3 grid(A.G, d->ndir, nc), block(256);
+        if (!scan_grid_fits((size_t)A.G * d->ndir * nc, lds)) return ASR_ERR_ARG;
 #define LAUNCH_(K, U) \
-        do { hipFuncSetAttribute((const void*)K<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        do { if (hipFuncSetAttribute((const void*)K<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                 return ASR_ERR_LAUNCH; \
              hipLaunchKernelGGL((K<U>), grid, block, lds, stream, Al); } while (0)
         if (!backward) {
             if (fused_cln) {
-                hipFuncSetAttribute((const void*)lstm_scan_fwd_cln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (hipFuncSetAttribute((const void*)lstm_scan_fwd_cln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) != hipSuccess) return ASR_ERR_LAUNCH;
                 hipLaunchKernelGGL(lstm_scan_fwd_cln_kernel, grid, block, lds, stream, Al);
             } else if (UT == 1) LAUNCH_(lstm_scan_fwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_fwd_kernel, 2);
             else LAUNCH_(lstm_scan_fwd_kernel, 4);

@@ -649,6 +649,15 @@ class Network(object):
         self.dropout_step = 0
         self._drop_ids = []
 
+    def set_precision(self, precision):
+        """'f32' (default: every product exact fp32 MFMA) or 'bf16', the optional mode of BASELINE.json's
+        north_star: the large GEMMs (input projections, output layer, dX and weight-gradient contractions) round
+        their operands to bf16 and accumulate in fp32; the recurrences stay fp32.  Process-wide (asr_amd.ops)."""
+        if precision not in ('f32', 'bf16'):
+            raise ValueError('precision must be f32 or bf16')
+        ops.GEMM_BF16 = precision == 'bf16'
+        self.precision = precision
+
     # ---- construction -------------------------------------------------------------------------
     def add_pair(self, pair, spec_per_dir):
         self.pairs.append(pair)

@@ -21,6 +21,10 @@ def _chk2d(t):
 
 
 _gemm_ws = {}
+GEMM_BF16 = False      # the optional bf16 mode (set through engine.Network.set_precision): products with at
+                       # least BF16_MIN_WORK multiply-adds run with bf16 operands, fp32 accumulate (keeping the
+                       # weight-gradient contractions in fp32 changed no measured error at cfg3 and cost 4 ms)
+BF16_MIN_WORK = 1 << 24
 
 
 def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
@@ -34,9 +38,10 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
     if ws is None:
         ws = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=Cm.device)     # split-K partials
         _gemm_ws[key] = ws
-    check(_lib.lib().asr_gemm_f32_ws(int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B),
-                                     max(B.stride(0), 1), beta, _p(Cm), max(Cm.stride(0), 1), _p(bias),
-                                     _p(ws), ws.numel() * 4, _s()), 'asr_gemm_f32_ws')
+    L = _lib.lib()
+    fn = L.asr_gemm_bf16_ws if (GEMM_BF16 and M * N * K >= BF16_MIN_WORK) else L.asr_gemm_f32_ws
+    check(fn(int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B), max(B.stride(0), 1), beta,
+             _p(Cm), max(Cm.stride(0), 1), _p(bias), _p(ws), ws.numel() * 4, _s()), 'asr_gemm_*_ws')
     return Cm
 
 

@@ -257,6 +257,8 @@ def main():
     ap.add_argument('--cfg', type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help='3 = the headline workload (default); 2/4/5 = the other training configs of '
                          'BASELINE.json, reported for DESIGN.md only')
+    ap.add_argument('--bf16', action='store_true', help='the optional bf16 mode (large GEMMs with bf16 operands); '
+                                                        'reported as dtype bf16-gemm, never the default')
     ap.add_argument('--selftest-cpu', action='store_true',
                     help='rehearse the N-rank protocol on the CPU over gloo (no kernels; for tests)')
     args = ap.parse_args()
@@ -283,6 +285,8 @@ def main():
 
     net = build_deep_hyperlstm('hyper', None, None, N_IN, N_LAYERS, N_UNITS, N_HYPER, N_Z, N_OUT, 1.0,
                                True, 0, device=dev, seed=1234)
+    if args.bf16:
+        net.set_precision('bf16')
     ar = dp.GradAllReduce(net)
     batches = []
     for i in range(args.pool):
@@ -346,7 +350,8 @@ def main():
                     scan_share_of_step=float(sum(t for _, _, t in bwd + fwd)) / (dt * 1e3))
         out = dict(metric='train frames/sec (node) 4x512 HyperLSTM', value=frames / dt, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='bf16-gemm/f32-scan' if args.bf16 else 'f32', data='synthetic',
                    config=dict(workload='cfg3: 4x512 HyperLSTM (H=128,Z=64) bidirectional, C=3436, '
                                         'two concatenated WSJ-shaped utterances per row, fwd+BPTT+'
                                         'all-reduce+Adam', per_gpu_batch=BATCH, global_batch=BATCH * world,

@@ -43,6 +43,13 @@ int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, co
                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
                     size_t ws_bytes, asr_stream_t stream);
 
+/* The optional bf16 mode of K1 (BASELINE.json north_star): tensors stay fp32 in memory, both
+ * operands are rounded to bf16 (nearest even) on the way into LDS and multiplied with bf16 MFMA, fp32 accumulate.
+ * Bound measured against the float64 oracle at the full-width configs: tests/test_gpu_bf16.py. */
+int asr_gemm_bf16_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
+                     size_t ws_bytes, asr_stream_t stream);
+
 /* dst[b][a][:] = src[a][b][:]  -- input.dimshuffle(1,0,2), libs/lhuclstm_layers.py:181,213 */
 int asr_swap01(const float* src, float* dst, int A, int B, int D, int ld_src, int ld_dst,
                asr_stream_t stream);

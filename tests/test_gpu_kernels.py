@@ -157,25 +157,35 @@ def test_seq_pool_kernels():
             assert relerr(got, dx_ref) < 1e-6
 
 
-def test_softmax_ce_kernel():
+@pytest.mark.parametrize('C', [3436, 61, 6, 4174, 1024, 5000, 7001, 4097])
+def test_softmax_ce_kernel(C):
+    """Both kernels (row in registers: C % 4 == 0 and C <= 6144; three-pass otherwise), every output, ties in
+    the argmax (first occurrence, like numpy / Theano), probabilities and log-posteriors."""
     from asr_amd import ops
     rng = np.random.default_rng(2)
-    B, T, C = 4, 9, 3436
+    B, T = 4, 9
     lg = (rng.standard_normal((T * B, C)) * 4).astype(np.float32)
+    lg[3, C // 2] = lg[3, C - 1] = lg[3].max() + 1.0          # a tie: the first one wins
     y = rng.integers(0, C, (B, T)).astype(np.int32)
     m = (rng.random((B, T)) > 0.3).astype(np.float32)
-    dl = torch.empty(T * B, C, device='cuda'); rce = torch.empty(T * B, device='cuda')
-    rok = torch.empty(T * B, device='cuda'); pred = torch.empty(B, T, dtype=torch.int32, device='cuda')
-    out = torch.empty(B, T, C, device='cuda')
-    ops.softmax_ce(torch.from_numpy(lg).cuda(), C, B, T, target=torch.from_numpy(y).cuda(),
-                   tmask=torch.from_numpy(m).cuda(), scale=1.0 / B, dlogits=dl, row_ce=rce, row_ok=rok,
-                   pred=pred, out_mode=1, out=out)
     lgb = lg.reshape(T, B, C).transpose(1, 0, 2).astype(np.float64)
     cost, s, p, dlo = O.softmax_ce(lgb, y, m.astype(np.float64))
-    assert abs(rce.sum().item() - s) / s < 1e-5
-    assert (pred.cpu().numpy() == p).all()
-    assert relerr(dl.cpu().numpy().reshape(T, B, C).transpose(1, 0, 2), dlo) < 1e-5
-    assert np.max(np.abs(out.cpu().numpy() - O.log_softmax(lgb))) < 2e-5
+    for mode in (1, 2):
+        dl = torch.empty(T * B, C, device='cuda'); rce = torch.empty(T * B, device='cuda')
+        rok = torch.empty(T * B, device='cuda'); pred = torch.empty(B, T, dtype=torch.int32, device='cuda')
+        out = torch.empty(B, T, C, device='cuda')
+        ops.softmax_ce(torch.from_numpy(lg).cuda(), C, B, T, target=torch.from_numpy(y).cuda(),
+                       tmask=torch.from_numpy(m).cuda(), scale=1.0 / B, dlogits=dl, row_ce=rce, row_ok=rok,
+                       pred=pred, out_mode=mode, out=out)
+        assert abs(rce.sum().item() - s) / s < 1e-5
+        assert (pred.cpu().numpy() == p).all() and pred.cpu().numpy()[3 % B, 3 // B] == C // 2
+        assert abs(rok.sum().item() - ((p == y) * m).sum()) < 1e-6
+        assert relerr(dl.cpu().numpy().reshape(T, B, C).transpose(1, 0, 2), dlo) < 1e-5
+        ref = O.log_softmax(lgb)
+        if mode == 1:
+            assert np.max(np.abs(out.cpu().numpy() - ref)) < 2e-5
+        else:
+            assert relerr(out.cpu().numpy(), np.exp(ref)) < 1e-5
 
 
 def test_lstm_pack_modes_against_their_definitions():
