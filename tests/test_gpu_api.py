@@ -60,6 +60,35 @@ def test_forward_lstm2_cli_writes_log_posteriors(tmp_path):
         assert np.allclose(np.exp(m.astype(np.float64)).sum(axis=1), 1.0, atol=1e-5)
 
 
+def test_forward_lstm2_cli_skip_frames(tmp_path):
+    """bin/forward_lstm2.py:86-102 with --skip 3: the net sees every third frame (libs/utils.py:208-229), its
+    log-posteriors are repeated 3 times along time and trimmed to the utterance (numpy.repeat un-skipping, the
+    idiom test/test_libs_utils.py:43-51 pins); an utterance shorter than the skip still gets all its frames."""
+    from asr_amd import data, forward, kaldi_io, utils
+    from asr_amd.builders import build_deep_lstm
+    D, C_, N, SKIP = 7, 9, 16, 3
+    utts = data.synthetic_set(5, D, C_, min_len=2, max_len=20, seed=11)
+    fp, _ = _write_feats(tmp_path, utts)
+    net = build_deep_lstm(True, True, D, 2, N, 0, C_, 1.0, True, False, 0, device='cuda:0', seed=3)
+    vals = _perturb(net, 4)
+    model = str(tmp_path / 'm.pkl')
+    utils.save_network(net, None, 3, model)
+    out = str(tmp_path / 'post.ark')
+    rc = forward.main(['lstm2', '--input-dim', str(D), '--output-dim', str(C_), '--num-layers', '2', '--num-units',
+                       str(N), '--batch-size', '2', '--skip', str(SKIP), model, 'ark:' + fp, 'ark:' + out])
+    assert rc == 0
+    got = kaldi_io.read_mat_ark('ark:' + out)
+    assert [k for k, _ in got] == [u.uttid for u in utts]
+    onet = O.OracleNetwork(net.describe(), vals)
+    for (k, m), u in zip(got, utts):
+        T = u.features.shape[0]
+        sk = u.features[::SKIP]
+        want = np.repeat(np.log(onet.posteriors(sk[None], np.ones((1, len(sk))))[0]), SKIP, axis=0)[:T]
+        assert m.shape == (T, C_)
+        assert np.max(np.abs(m - want)) < 2e-5 * np.max(np.abs(want))
+        assert np.array_equal(m[0], m[min(SKIP, T) - 1])
+
+
 def test_forward_ivec_ln_lstmp_cli(tmp_path):
     from asr_amd import data, forward, kaldi_io, utils
     from asr_amd.gating_hyper_nets import deep_projection_ivector_ln_model
