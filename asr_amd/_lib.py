@@ -59,6 +59,7 @@ _SIGS = {
     'asr_gemm_f32': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp]),
     'asr_gemm_f32_ws': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
     'asr_gemm_bf16_ws': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
+    'asr_gemm_bf16x3_ws': (i32, [i32, i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
     'asr_swap01': (i32, [fp, fp, i32, i32, i32, i32, i32, fp]),
     'asr_ln_rows_fwd': (i32, [fp, i32, i32, fp, i32, fp, fp, i32, fp, fp, fp, fp, i32, fp]),
     'asr_ln_rows_bwd': (i32, [fp, i32, i32, fp, fp, fp, i32, fp, i32, fp]),

@@ -1,4 +1,5 @@
-// K1: exact-fp32 MFMA GEMM for the all-timestep projections and the weight-gradient contractions.
+// K1: fp32 GEMM for the all-timestep projections and the weight-gradient contractions: gemm_f32_kernel on the fp32
+// matrix cores, and gemm_split_kernel (further down) with fp32-grade products on the bf16 matrix cores.
 //   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C  (+ bias[N] broadcast over rows)
 // op = identity or transpose, row-major storage with leading dimensions.  Arithmetic is
 // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain, no reduced precision).
@@ -12,10 +13,8 @@
 #define BK 16
 #define LDSP 132   // padded row (floats): 128 + 4 keeps 16-B alignment and breaks bank aliasing
 
-// Optional bf16 mode (BASELINE.json north_star: "a stated bound in the optional bf16 mode"): the same kernel
-// with BF = true rounds both operands to bf16 (round to nearest even, v_cvt_pk_bf16_f32) while staging them
-// into LDS and multiplies with v_mfma_f32_32x32x16_bf16, fp32 accumulate; HBM tensors stay fp32.  LDS image
-// [k / 8][row][k % 8]: a lane's 8 consecutive k of its row are one conflict-free ds_read_b128.
+// The bf16 matrix cores are used by gemm_split_kernel below: for the optional bf16 mode (BASELINE.json north_star:
+// "a stated bound in the optional bf16 mode") and for fp32-grade products from split operands.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -26,7 +25,7 @@ __device__ __forceinline__ float ldg_op(const float* X, int ld, int r, int c, in
     return TR ? X[(size_t)c * ld + r] : X[(size_t)r * ld + c];
 }
 
-template <bool TA, bool TB, bool BF>
+template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, float alpha,
                                                         const float* __restrict__ A, int lda,
                                                         const float* __restrict__ B, int ldb,
@@ -35,8 +34,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
                                                         int kchunk, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDSP];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDSP];
-    __bf16 (*Ah)[2][BM][8] = (__bf16 (*)[2][BM][8])&As[0][0][0];      // bf16 images in the same storage
-    __bf16 (*Bh)[2][BN][8] = (__bf16 (*)[2][BN][8])&Bs[0][0][0];
 
     // XCD-aware tile order: blocks b and b+8 share an L2; give each XCD a contiguous strip of
     // tiles along N so the A row-panel is re-used from that L2.
@@ -100,29 +97,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         }
     };
     auto store_tiles = [&](int buf) {
-        if (BF) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int idx = e * 256 + tid;
-                if (TA) {                                   // 4 consecutive rows of one k
-                    const int k = idx / 32, m4 = (idx % 32) * 4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) Ah[buf][k >> 3][m4 + i][k & 7] = (__bf16)ra[e][i];
-                } else {                                    // 4 consecutive k of one row: one 8-byte store
-                    const int m = idx / 4, k4 = (idx % 4) * 4;
-                    *(bf16x4*)&Ah[buf][k4 >> 3][m][k4 & 7] = bf16x4{(__bf16)ra[e][0], (__bf16)ra[e][1], (__bf16)ra[e][2], (__bf16)ra[e][3]};
-                }
-                if (TB) {
-                    const int n = idx / 4, k4 = (idx % 4) * 4;
-                    *(bf16x4*)&Bh[buf][k4 >> 3][n][k4 & 7] = bf16x4{(__bf16)rb[e][0], (__bf16)rb[e][1], (__bf16)rb[e][2], (__bf16)rb[e][3]};
-                } else {
-                    const int k = idx / 32, n4 = (idx % 32) * 4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) Bh[buf][k >> 3][n4 + i][k & 7] = (__bf16)rb[e][i];
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = e * 256 + tid;
@@ -147,15 +121,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int lr = lane & 31, lk = lane >> 5;
     auto mfma_tile = [&](int buf) {
-        if (BF) {                                // K = 16 per instruction: lane half lk holds k = 8 lk .. 8 lk + 7
-            const bf16x8 a0 = *(const bf16x8*)&Ah[buf][lk][wm * 64 + lr][0], a1 = *(const bf16x8*)&Ah[buf][lk][wm * 64 + 32 + lr][0];
-            const bf16x8 b0 = *(const bf16x8*)&Bh[buf][lk][wn * 64 + lr][0], b1 = *(const bf16x8*)&Bh[buf][lk][wn * 64 + 32 + lr][0];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            return;
-        }
         // all LDS operands of the tile are requested up front (32 VGPRs): LDS returns in order, so the
         // first MFMAs start after the first reads and the rest of the read latency hides under them
         float a0[BK / 2], a1[BK / 2], b0[BK / 2], b1[BK / 2];
@@ -249,6 +214,253 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32-grade GEMM on the bf16 matrix cores ("bf16x3"): every fp32 operand element x is split while it is staged
+// into LDS into three bf16 values x = h + m + l (h = rn(x), m = rn(x - h), l = rn(x - h - m); the two
+// differences are exact in fp32 and 3 x 8 significand bits cover fp32's 24), and the product is the sum
+// of the partial products a_i * b_j, each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16:
+//   TERMS = 8: all but a_l * b_l          -> dropped part <= 2^-32 |a b|, below fp32's own product rounding
+//   TERMS = 6: also without a_m*b_l, a_l*b_m -> dropped part <= 2^-23 |a b| worst case
+//   TERMS = 1: a_h * b_h only (the plain bf16 mode)
+// 6 bf16 MFMAs (32 cycles each) replace the 8 v_mfma_f32_32x32x2_f32 (64 cycles each) of a 32x32x16 block.  How the
+// partial products are summed matters more than how many there are (see mfma_tile): measured against float64 on
+// Gaussian operands, K = 1024, the kernel has rms error 8.6e-8 and mean error 2e-10 of the result's rms, the fp32
+// MFMA kernel 2.1e-7 and 3e-11 (tools/ubench/gemm_split_rms.py, tests/test_gpu_kernels.py); 150-157 TFLOP/s on the
+// cfg3 shapes against 104-120.  A second set of accumulators for the correction terms (kept across the K loop) cost
+// the second resident workgroup per CU (118 TFLOP/s).
+// LDS images per operand and split part, chosen by the operand's storage order so that both the global
+// loads and the LDS stores are 16-byte / conflict-free:
+//   k contiguous in memory ([row][k]):  [k / 8][row][k % 8] bf16, written 8 B per lane, read ds_read_b128
+//   row contiguous in memory ([k][row]): [k][row] bf16 with 320-byte k rows, written 8 B per lane (4 rows of one
+//                                        k), read with the transposing ds_read_b64_tr_b16 (4 k x 16 rows per
+//                                        16-lane group): two reads give a lane the 8 k of its row
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define SPL_KROW 320                      // bytes per k row of the row-contiguous image: 128 bf16 + 64 B, so that the
+                                          // 4 k rows x 2 column groups of a transposed read fall on 64 distinct banks
+#define SPL_IMG (16 * SPL_KROW)           // bytes per image (>= 2 * 128 * 16 of the other layout)
+
+// two fp32 values -> packed bf16 pairs of their split parts (one v_cvt_pk_bf16_f32 per part)
+template <int NP>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned* out) {
+    out[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+    if (NP > 1) {
+        const float r0 = x0 - __uint_as_float(out[0] << 16), r1 = x1 - __uint_as_float(out[0] & 0xffff0000u);
+        out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+        const float q0 = r0 - __uint_as_float(out[1] << 16), q1 = r1 - __uint_as_float(out[1] & 0xffff0000u);
+        out[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
+    }
+}
+
+template <bool TA, bool TB, int TERMS>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K, float alpha,
+                                                          const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb,
+                                                          float beta, float* __restrict__ C, int ldc,
+                                                          const float* __restrict__ bias, int ntn,
+                                                          int kchunk, float* __restrict__ part) {
+    constexpr int NP = TERMS == 1 ? 1 : 3;
+    constexpr bool AKM = TA, BKM = !TB;        // operand stored [k][row] (row contiguous)
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][NP][SPL_IMG];   // [buf][A|B][part]
+
+    int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        int q = nblk / 8, r = nblk % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    f32x4 ra[2], rb[2];
+    const bool vecA = ((((uintptr_t)A) & 15) == 0) && ((lda & 3) == 0);
+    const bool vecB = ((((uintptr_t)B) & 15) == 0) && ((ldb & 3) == 0);
+    auto ld4 = [&](const float* X, int ld, int r, int c, int R, int Cc, bool vec) -> f32x4 {
+        if (vec && r < R && c + 3 < Cc) return *(const f32x4*)(X + (size_t)r * ld + c);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (c + i < Cc) v[i] = X[(size_t)r * ld + c + i];
+        }
+        return v;
+    };
+    // thread -> elements.  [k][row] storage: k pair kp = tid / 32 (rows k0 + 2 kp, + 1), 4 columns at 4 (tid % 32).
+    //                      [row][k] storage: e = 0, 1: row (e * 256 + tid) / 4, 4 k at 4 ((e * 256 + tid) % 4).
+    const int kp = tid >> 5, c4 = (tid & 31) * 4;
+    auto load_tiles_fast = [&](f32x4* ra, f32x4* rb, int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 256 + tid;
+            if (AKM) ra[e] = *(const f32x4*)(A + (size_t)(k0 + 2 * kp + e) * lda + m0 + c4);
+            else     ra[e] = *(const f32x4*)(A + (size_t)(m0 + idx / 4) * lda + k0 + (idx % 4) * 4);
+            if (BKM) rb[e] = *(const f32x4*)(B + (size_t)(k0 + 2 * kp + e) * ldb + n0 + c4);
+            else     rb[e] = *(const f32x4*)(B + (size_t)(n0 + idx / 4) * ldb + k0 + (idx % 4) * 4);
+        }
+    };
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 256 + tid;
+            if (AKM) ra[e] = ld4(A, lda, k0 + 2 * kp + e, m0 + c4, K, M, vecA);
+            else     ra[e] = ld4(A, lda, m0 + idx / 4, k0 + (idx % 4) * 4, M, K, vecA);
+            if (BKM) rb[e] = ld4(B, ldb, k0 + 2 * kp + e, n0 + c4, K, N, vecB);
+            else     rb[e] = ld4(B, ldb, n0 + idx / 4, k0 + (idx % 4) * 4, N, K, vecB);
+        }
+    };
+    auto store_op = [&](unsigned char (*img)[SPL_IMG], const f32x4* r, bool kmaj, float sg) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            unsigned w0[3], w1[3];
+            split_pair<NP>(r[e][0] * sg, r[e][1] * sg, w0);
+            split_pair<NP>(r[e][2] * sg, r[e][3] * sg, w1);
+            const int idx = e * 256 + tid;
+            // [k][row] storage: 4 rows c4.. of k = 2 kp + e;   [row][k] storage: row idx / 4, k = 4 (idx % 4) ..
+            const size_t off = kmaj ? (size_t)(2 * kp + e) * SPL_KROW + c4 * 2
+                                    : ((size_t)(((idx % 4) * 4) >> 3) * 128 + idx / 4) * 16 + (((idx % 4) * 4) & 7) * 2;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *(u32x2*)(img[p] + off) = u32x2{w0[p], w1[p]};
+        }
+    };
+    // K-tile t enters with the sign (-1)^t on its A operand and is joined with the same sign: see mfma_tile
+    auto sgn = [](int t) { return (TERMS > 1 && (t & 1)) ? -1.0f : 1.0f; };
+    auto store_tiles = [&](int t) {
+        store_op(sm[t & 1][0], ra, AKM, sgn(t));
+        store_op(sm[t & 1][1], rb, BKM, 1.0f);
+    };
+    const int lr = lane & 31, lk = lane >> 5;
+    // transposed read: lane 4q + p of a 16-lane group addresses k row q, rows 4p .. 4p + 3 of the group's 16 rows
+    // and receives, for row (lane & 15) of the group, the 4 k of the block (cdna_hip_programming.md T10)
+    const int tr_off = (8 * lk + ((lane >> 2) & 3)) * SPL_KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto frag = [&](const unsigned char* img, int row0, bool kmaj) -> bf16x8 {
+        if (kmaj) {
+            typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+            const unsigned char* p = img + tr_off + row0 * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * SPL_KROW));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        return *(const bf16x8*)(img + ((size_t)lk * 128 + row0 + lr) * 16);
+    };
+#define SPL_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc_, 0, 0, 0)
+    auto mfma_tile = [&](int tile) {
+        const int buf = tile & 1;
+        const float sg = sgn(tile);
+        bf16x8 a[2][NP], b[2][NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][p] = frag(sm[buf][0][p], wm * 64 + i * 32, AKM);
+                b[i][p] = frag(sm[buf][1][p], wn * 64 + i * 32, BKM);
+            }
+        if (TERMS == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) SPL_MFMA(acc[i][j], a[i][0], b[j][0]);
+        } else {
+            // The bf16 MFMA truncates its fp32 accumulation toward -inf (measured: mean error -0.5 ulp of the accumulator
+            // per instruction, where v_mfma_f32_32x32x2_f32 rounds to nearest); a bias of one sign survives an LSTM's
+            // cell integration far better than rounding noise.  So the TERMS products of a K-tile form a chain from a
+            // zero accumulator and join the running sum with a round-to-nearest v_fma_f32, and K-tiles alternate in
+            // sign: odd tiles multiply -A (the split of -x is exactly minus the split of x) and are subtracted, so the
+            // truncation pushes the sum down on even tiles and up on odd ones and cancels in expectation.
+            constexpr int pa[8] = {0, 0, 1, 1, 0, 2, 1, 2}, pb[8] = {0, 1, 0, 1, 2, 0, 2, 1};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 tmp;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tmp[e] = 0.0f;
+#pragma unroll
+                    for (int t = TERMS - 1; t >= 0; --t) SPL_MFMA(tmp, a[i][pa[t] < NP ? pa[t] : 0], b[j][pb[t] < NP ? pb[t] : 0]);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(tmp[e], sg, acc[i][j][e]);
+                }
+        }
+    };
+#undef SPL_MFMA
+
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int Ksave = K;
+    K = kend;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nk_full = (kend - kbeg) / BK;
+    const bool interior = vecA && vecB && (m0 + BM <= M) && (n0 + BN <= N) && nk_full > 0;
+    if (interior) {
+        load_tiles_fast(ra, rb, kbeg);
+        store_tiles(0);
+        __syncthreads();
+        // one iteration per trip, not unrolled: an unrolled pair made the register allocator move the 64 accumulator
+        // registers between the halves (v_mov behind the MFMA latency).  Loads two tiles ahead and an MFMA / split-VALU
+        // interleave (sched_group_barrier) were measured and changed nothing: 162 vs 170 TFLOP/s
+#pragma unroll 1
+        for (int kt = 0; kt + 1 < nk_full; ++kt) {
+            load_tiles_fast(ra, rb, kbeg + (kt + 1) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(kt);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tiles(kt + 1);
+            __syncthreads();
+        }
+        if (nk > nk_full) {                                 // K tail: one guarded tile
+            load_tiles(kbeg + nk_full * BK);
+            mfma_tile(nk_full - 1);
+            store_tiles(nk_full);
+            __syncthreads();
+            mfma_tile(nk_full);
+        } else {
+            mfma_tile(nk_full - 1);
+        }
+    } else {
+        load_tiles(kbeg);
+        store_tiles(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+            mfma_tile(kt);
+            if (kt + 1 < nk) store_tiles(kt + 1);
+            __syncthreads();
+        }
+    }
+    K = Ksave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = (bias && !part) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                const float s = acc[i][j][e];
+                if (part) { part[((size_t)blockIdx.y * M + row) * N + col] = s; continue; }
+                float* p = C + (size_t)row * ldc + col;
+                float v = alpha * s + bv;
+                if (beta != 0.0f) v += beta * (*p);
+                *p = v;
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ns,
                                                                   int M, int N, float alpha, float beta,
                                                                   float* __restrict__ C, int ldc,
@@ -275,7 +487,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 
 // ws (optional): scratch for split-K partials.  Split-K is used when the output has too few tiles to
 // fill the chip and K is long (the weight-gradient contractions, K = T*B).
-static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+static int gemm_launch(int mode, int transA, int transB, int M, int N, int K, float alpha, const float* A,
                        int lda, const float* B, int ldb, float beta, float* C, int ldc,
                        const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (M < 0 || N < 0 || K < 0 || !C) return ASR_ERR_ARG;
@@ -306,9 +518,13 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
     dim3 grid(tiles, ns), block(256);
 #define LAUNCH(TA_, TB_)                                                                                \
     do {                                                                                                \
-        if (bf16) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, true>), grid, block, 0, stream, M, N, K, alpha, A, \
+        if (mode == 6) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 6>), grid, block, 0, stream, M, N, K, alpha, A, \
                                      lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);               \
-        else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, false>), grid, block, 0, stream, M, N, K, alpha, A, \
+        else if (mode == 8) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 8>), grid, block, 0, stream, M, N, K, alpha, A, \
+                                     lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);               \
+        else if (mode == 1) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1>), grid, block, 0, stream, M, N, K, alpha, A, \
+                                     lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);               \
+        else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, block, 0, stream, M, N, K, alpha, A, \
                                 lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);                    \
     } while (0)
     if (!transA && !transB) LAUNCH(false, false);
@@ -330,13 +546,23 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
 extern "C" int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A,
                                int lda, const float* B, int ldb, float beta, float* C, int ldc,
                                const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
-    return gemm_launch(false, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, stream);
+    return gemm_launch(0, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, stream);
 }
 // the optional bf16 mode: fp32 tensors in memory, operands rounded to bf16 on the way into LDS, fp32 accumulate
+// (gemm_split_kernel with the leading term only)
 extern "C" int asr_gemm_bf16_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A,
                                 int lda, const float* B, int ldb, float beta, float* C, int ldc,
                                 const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
-    return gemm_launch(true, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, stream);
+    return gemm_launch(1, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, stream);
+}
+
+// fp32-grade products from split bf16 operands (gemm_split_kernel): terms = 8, 6 (or 1: plain bf16 in the same kernel)
+extern "C" int asr_gemm_bf16x3_ws(int terms, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                                  int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                                  const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
+    if (terms != 8 && terms != 6 && terms != 1) return ASR_ERR_ARG;
+    return gemm_launch(terms, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws,
+                       ws_bytes, stream);
 }
 
 extern "C" int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A,

@@ -650,12 +650,15 @@ class Network(object):
         self._drop_ids = []
 
     def set_precision(self, precision):
-        """'f32' (default: every product exact fp32 MFMA) or 'bf16', the optional mode of BASELINE.json's
-        north_star: the large GEMMs (input projections, output layer, dX and weight-gradient contractions) round
-        their operands to bf16 and accumulate in fp32; the recurrences stay fp32.  Process-wide (asr_amd.ops)."""
-        if precision not in ('f32', 'bf16'):
-            raise ValueError('precision must be f32 or bf16')
-        ops.GEMM_BF16 = precision == 'bf16'
+        """How the large GEMMs (input projections, output layer, dX, weight-gradient contractions) multiply; the
+        recurrences, layer norms, softmax and the optimiser are fp32 in every mode.  Process-wide (asr_amd.ops).
+          'f32x3' (default) fp32-grade products on the bf16 matrix cores from operands split into three bf16 parts;
+          'f32'   fp32 MFMA throughout;
+          'bf16'  the optional mode of BASELINE.json's north_star: operands rounded to bf16, fp32 accumulate,
+                  with the measured bound of tests/test_gpu_bf16.py."""
+        if precision not in ops.GEMM_TERMS:
+            raise ValueError('precision must be one of %s' % sorted(ops.GEMM_TERMS))
+        ops.PRECISION = precision
         self.precision = precision
 
     # ---- construction -------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C-ABI (include/asr_amd.h).  torch is used for device memory
 and streams only; every arithmetic op below is a HIP kernel in libasr_amd.so."""
 import ctypes as C
+import os
 import torch
 
 from . import _lib
@@ -21,10 +22,18 @@ def _chk2d(t):
 
 
 _gemm_ws = {}
-GEMM_BF16 = False      # the optional bf16 mode (set through engine.Network.set_precision): products with at
-                       # least BF16_MIN_WORK multiply-adds run with bf16 operands, fp32 accumulate (keeping the
-                       # weight-gradient contractions in fp32 changed no measured error at cfg3 and cost 4 ms)
-BF16_MIN_WORK = 1 << 24
+# How the large products (at least SPLIT_MIN_WORK multiply-adds: input projections, output layer, dX, weight-gradient
+# contractions) are multiplied; set through engine.Network.set_precision, process-wide:
+#   'f32x3' fp32-grade on the bf16 matrix cores: operands split into three bf16 parts on the way into LDS, 6 partial
+#           products accumulated in fp32 (asr_gemm_bf16x3_ws; error against float64 at or below the fp32 MFMA kernel's)
+#   'f32'   v_mfma_f32_32x32x2_f32 throughout (asr_gemm_f32_ws)
+#   'bf16'  the optional bf16 mode: operands rounded to bf16, fp32 accumulate (keeping the weight-gradient
+#           contractions in fp32 changed no measured error at cfg3 and cost 4 ms)
+# Small products always take the fp32 MFMA kernel.
+GEMM_TERMS = {'f32': 0, 'f32x3': 6, 'bf16': 1}
+DEFAULT_PRECISION = os.environ.get('ASR_PRECISION', 'f32x3')
+PRECISION = DEFAULT_PRECISION
+SPLIT_MIN_WORK = 1 << 24
 
 
 def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
@@ -39,9 +48,13 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
         ws = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=Cm.device)     # split-K partials
         _gemm_ws[key] = ws
     L = _lib.lib()
-    fn = L.asr_gemm_bf16_ws if (GEMM_BF16 and M * N * K >= BF16_MIN_WORK) else L.asr_gemm_f32_ws
-    check(fn(int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B), max(B.stride(0), 1), beta,
-             _p(Cm), max(Cm.stride(0), 1), _p(bias), _p(ws), ws.numel() * 4, _s()), 'asr_gemm_*_ws')
+    terms = GEMM_TERMS[PRECISION] if M * N * K >= SPLIT_MIN_WORK else 0
+    args = (int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B), max(B.stride(0), 1), beta,
+            _p(Cm), max(Cm.stride(0), 1), _p(bias), _p(ws), ws.numel() * 4, _s())
+    if terms:
+        check(L.asr_gemm_bf16x3_ws(terms, *args), 'asr_gemm_bf16x3_ws')
+    else:
+        check(L.asr_gemm_f32_ws(*args), 'asr_gemm_f32_ws')
     return Cm
 
 

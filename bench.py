@@ -257,8 +257,11 @@ def main():
     ap.add_argument('--cfg', type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help='3 = the headline workload (default); 2/4/5 = the other training configs of '
                          'BASELINE.json, reported for DESIGN.md only')
-    ap.add_argument('--bf16', action='store_true', help='the optional bf16 mode (large GEMMs with bf16 operands); '
-                                                        'reported as dtype bf16-gemm, never the default')
+    ap.add_argument('--precision', default=None, choices=['f32x3', 'f32', 'bf16'],
+                    help='how the large GEMMs multiply (asr_amd.ops): f32x3 = fp32-grade products from operands split '
+                         'into three bf16 parts (default), f32 = fp32 MFMA throughout, bf16 = the optional bf16 mode')
+    ap.add_argument('--bf16', action='store_true', help='same as --precision bf16: reported as dtype bf16-gemm, '
+                                                        'never the default')
     ap.add_argument('--selftest-cpu', action='store_true',
                     help='rehearse the N-rank protocol on the CPU over gloo (no kernels; for tests)')
     args = ap.parse_args()
@@ -286,7 +289,11 @@ def main():
     net = build_deep_hyperlstm('hyper', None, None, N_IN, N_LAYERS, N_UNITS, N_HYPER, N_Z, N_OUT, 1.0,
                                True, 0, device=dev, seed=1234)
     if args.bf16:
-        net.set_precision('bf16')
+        args.precision = 'bf16'
+    if args.precision:
+        net.set_precision(args.precision)
+    from asr_amd import ops
+    precision = ops.PRECISION
     ar = dp.GradAllReduce(net)
     batches = []
     for i in range(args.pool):
@@ -351,11 +358,14 @@ def main():
         out = dict(metric='train frames/sec (node) 4x512 HyperLSTM', value=frames / dt, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
                    higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='bf16-gemm/f32-scan' if args.bf16 else 'f32', data='synthetic',
+                   dtype='bf16-gemm/f32-scan' if precision == 'bf16' else 'f32', data='synthetic',
                    config=dict(workload='cfg3: 4x512 HyperLSTM (H=128,Z=64) bidirectional, C=3436, '
                                         'two concatenated WSJ-shaped utterances per row, fwd+BPTT+'
                                         'all-reduce+Adam', per_gpu_batch=BATCH, global_batch=BATCH * world,
-                               parallelism='dp%d' % world),
+                               parallelism='dp%d' % world,
+                               gemm={'f32x3': 'fp32-grade: operands split into 3 bf16 parts, 6 bf16-MFMA partial '
+                                              'products, fp32 accumulate (error vs float64 below the fp32 MFMA kernel)',
+                                     'f32': 'v_mfma_f32_32x32x2_f32', 'bf16': 'operands rounded to bf16'}[precision]),
                    roofline=roof)
         out.update(clock.summary())
         if world == 1 and not args.no_cpu_baseline:

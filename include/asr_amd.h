@@ -49,6 +49,12 @@ int asr_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, co
 int asr_gemm_bf16_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                      const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
                      size_t ws_bytes, asr_stream_t stream);
+/* fp32-grade products on the bf16 matrix cores: every operand element is split into three bf16 parts while it
+ * is staged into LDS and `terms` partial products are accumulated in fp32 (8: error below fp32's own product
+ * rounding; 6: <= 2^-23 |a b|; 1: plain bf16 in the same kernel).  Same T.dot call sites as asr_gemm_f32_ws. */
+int asr_gemm_bf16x3_ws(int terms, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                       const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
+                       size_t ws_bytes, asr_stream_t stream);
 
 /* dst[b][a][:] = src[a][b][:]  -- input.dimshuffle(1,0,2), libs/lhuclstm_layers.py:181,213 */
 int asr_swap01(const float* src, float* dst, int A, int B, int D, int ld_src, int ld_dst,

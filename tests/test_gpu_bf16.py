@@ -79,7 +79,7 @@ def test_bf16_mode_meets_the_stated_bound(cfg, max_len):
         net.check_status()
         grads = net.get_all_grad_values()
     finally:
-        net.set_precision('f32')
+        net.set_precision(ops.DEFAULT_PRECISION)
     valid = b['mask'] > 0
     e_lp = float(np.abs(lp - olp)[valid].max())
     gn = [np.linalg.norm(g) for g in og]
@@ -103,4 +103,4 @@ def test_bf16_mode_meets_the_stated_bound(cfg, max_len):
     assert np.isfinite(e_lp) and np.isfinite(e_all)
     if cfg == 3:
         assert e_lp <= BOUND_LOGPOST and e_ce <= BOUND_CE and e_all <= BOUND_GRAD_ALL, (e_lp, e_ce, e_all)
-    assert not ops.GEMM_BF16
+    assert ops.PRECISION == ops.DEFAULT_PRECISION

@@ -34,6 +34,45 @@ def test_gemm(ta, tb, M, N, K):
     assert (got[:, N:] == C0[:, N:]).all()          # the strided view's neighbours are untouched
 
 
+@pytest.mark.parametrize('terms', [6, 8])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_split_bf16_is_fp32_grade(ta, tb, terms):
+    """asr_gemm_bf16x3_ws (operands split into three bf16 parts, 6 or 8 partial products, fp32 accumulate) against
+    float64, next to asr_gemm_f32_ws (fp32 MFMA) on the same inputs: the error, taken relative to |A|.|B| element by
+    element, stays below 1.5e-6 and is not above the fp32 MFMA kernel's by more than rounding scatter.  Operands
+    span +-6 powers of e so that every split part matters; shapes cover edge tiles, K tails, split-K, alpha / beta /
+    bias and a strided output."""
+    from asr_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11 + 2 * ta + tb)
+    ws = torch.empty(16 << 20, device='cuda')
+    for M, N, K in ((128, 128, 64), (200, 136, 50), (37, 300, 1000), (256, 128, 8192), (5, 7, 3), (1000, 515, 123)):
+        sa, sb = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
+        A = (rng.standard_normal(sa) * np.exp(2 * rng.standard_normal(sa))).astype(np.float32)
+        B = (rng.standard_normal(sb) * np.exp(2 * rng.standard_normal(sb))).astype(np.float32)
+        C0 = rng.standard_normal((M, N + 3)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        dA, dB, db = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(bias).cuda()
+        opA, opB = (A.T if ta else A).astype(np.float64), (B.T if tb else B).astype(np.float64)
+        ref = 0.5 * (opA @ opB) + C0[:, :N] + bias
+        scale = 0.5 * (np.abs(opA) @ np.abs(opB)) + np.abs(C0[:, :N]) + np.abs(bias)
+        errs = []
+        for split in (True, False):
+            dC = torch.from_numpy(C0).cuda()
+            args = (ta, tb, M, N, K, 0.5, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], 1.0, dC.data_ptr(), N + 3,
+                    db.data_ptr(), ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+            rc = L.asr_gemm_bf16x3_ws(terms, *args) if split else L.asr_gemm_f32_ws(*args)
+            assert rc == 0
+            got = dC.cpu().numpy()
+            assert (got[:, N:] == C0[:, N:]).all()
+            errs.append(float(np.max(np.abs(got[:, :N] - ref) / scale)))
+        print('M=%d N=%d K=%d ta=%d tb=%d terms=%d: split %.2e, fp32 MFMA %.2e' % (M, N, K, ta, tb, terms, *errs))
+        assert errs[0] < 1.5e-6, (M, N, K, errs)
+        assert errs[0] < 1.5 * errs[1] + 1e-7, (M, N, K, errs)
+    assert L.asr_gemm_bf16x3_ws(5, 0, 0, 8, 8, 8, 1.0, dA.data_ptr(), 8, dB.data_ptr(), 8, 0.0, dC.data_ptr(), 8, None,
+                                None, 0, torch.cuda.current_stream().cuda_stream) == -1
+
+
 def test_ln_rows_and_colreduce():
     from asr_amd import ops
     rng = np.random.default_rng(1)
