@@ -247,6 +247,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <int NP>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned* out) {
     out[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+#if defined(SPL_ABL) && SPL_ABL == 1
+    if (NP > 1) { out[1] = out[0]; out[2] = out[0]; return; }
+#endif
     if (NP > 1) {
         const float r0 = x0 - __uint_as_float(out[0] << 16), r1 = x1 - __uint_as_float(out[0] & 0xffff0000u);
         out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
@@ -364,6 +367,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+#if defined(SPL_ABL) && SPL_ABL == 4
+                if (p > 0) { a[i][p] = a[i][0]; b[i][p] = b[i][0]; continue; }
+#endif
                 a[i][p] = frag(sm[buf][0][p], wm * 64 + i * 32, AKM);
                 b[i][p] = frag(sm[buf][1][p], wn * 64 + i * 32, BKM);
             }
@@ -388,7 +394,15 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
 #pragma unroll
                     for (int e = 0; e < 16; ++e) tmp[e] = 0.0f;
 #pragma unroll
+#if defined(SPL_ABL) && SPL_ABL == 2
+                    for (int t = TERMS - 1; t >= 0; --t) SPL_MFMA(acc[i][j], a[i][pa[t] < NP ? pa[t] : 0], b[j][pb[t] < NP ? pb[t] : 0]);
+                    continue;
+#endif
+#if defined(SPL_ABL) && SPL_ABL == 3
+                    for (int t = 2; t >= 0; --t) SPL_MFMA(tmp, a[i][t], b[j][t]);
+#else
                     for (int t = TERMS - 1; t >= 0; --t) SPL_MFMA(tmp, a[i][pa[t] < NP ? pa[t] : 0], b[j][pb[t] < NP ? pb[t] : 0]);
+#endif
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(tmp[e], sg, acc[i][j][e]);
                 }

@@ -33,6 +33,8 @@ TOL_F, TOL_G = 2e-5, 1e-4
 
 
 def _record(**kw):
+    from asr_amd import ops
+    kw['precision'] = ops.PRECISION              # how the large GEMMs multiplied (asr_amd.ops)
     d = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(d):
         with open(os.path.join(d, 'parity_r02.jsonl'), 'a') as f:

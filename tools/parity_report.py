@@ -10,6 +10,7 @@ for r in recs:
     by['cfg%d' % r['cfg']] = r                 # the last run of each config wins
 out = dict(source='tests/test_gpu_longt.py on one MI355X, float64 numpy oracle (oracle/asr_oracle.py)',
            error_measure='max|a-b| / max|b| per tensor (gradients: + 1e-3 of the largest gradient tensor in the denominator)',
+           precision=sorted({r.get('precision', 'f32x3') for r in by.values() if r['cfg'] < 100}),
            configs=by)
 with open(os.path.join(ROOT, 'profiles', 'parity_%s.json' % tag), 'w') as f:
     json.dump(out, f, indent=1, sort_keys=True)
