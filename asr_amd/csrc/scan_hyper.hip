@@ -812,15 +812,16 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         STAMP(7);
         // ---- S5: own rows of [W_xhat[:N] ; W_hhat] times the gathered hyper gate grads; gather of the
         // R x KQ partial W_h.da pieces (4 own units x 16 batch = 256 B each) of the own unit block
+        // (the partial pieces are requested first and parked in LDS only after the Rw product below: a store behind the
+        // load would make hipcc wait for it before the dgx loads are even issued: two memory latencies in a row)
+        const int pc5 = tid >> 4, f45 = tid & 15;             // piece = (member s, K slice kq2)
+        f32x4 pv5;
         {
-            const int pc = tid >> 4, f4 = tid & 15;           // piece = (member s, K slice kq2)
-            const int s_ = pc / KQ, kq2 = pc % KQ;
+            const int s_ = pc5 / KQ, kq2 = pc5 % KQ;
             const int ul = kr * 4;                            // own units inside the block
             const int tile = kq2 * MT + ul / 16;
-            f32x4 v = ldb_sc1_f4(px_rs, (unsigned)((((ul & 15) * 16) + f4 * 4) * 4),
-                                 (unsigned)(((((size_t)par * G + ub * R + (s_ < R ? s_ : 0)) * 4 + tile) * 256) * 4));
-            if (s_ >= R) v = f32x4{0, 0, 0, 0};
-            *(f32x4*)(rsum + ((size_t)pc * 16 + f4) * 4) = v;
+            pv5 = ldb_sc1_f4(px_rs, (unsigned)((((ul & 15) * 16) + f45 * 4) * 4),
+                             (unsigned)(((((size_t)par * G + ub * R + (s_ < R ? s_ : 0)) * 4 + tile) * 256) * 4));
         }
         {
             f32x4 acc = {0, 0, 0, 0};
@@ -845,6 +846,8 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             }
             *(f32x4*)(red + ((size_t)wave * 64 + lane) * 4) = acc;
         }
+        if (pc5 / KQ >= R) pv5 = f32x4{0, 0, 0, 0};
+        *(f32x4*)(rsum + ((size_t)pc5 * 16 + f45) * 4) = pv5;
         __syncthreads();
         // output rows i = q*4+reg: i<4 -> main unit i (lanes q==0, reg=i); i=4+uh -> hyper (q==1, reg=uh)
         if (wave == 0) {
