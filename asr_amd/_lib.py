@@ -71,6 +71,7 @@ _SIGS = {
     'asr_rowscale': (i32, [fp, i32, fp, i32, i32, fp, i32, i32, i32, fp]),
     'asr_dropout': (i32, [fp, i32, fp, i32, i32, i32, f32, C.c_ulonglong, C.c_ulonglong, fp]),
     'asr_affine_rows': (i32, [fp, i32, fp, fp, fp, fp, i32, i32, i32, fp, i32, i32, i32, fp]),
+    'asr_var_costs': (i32, [fp, fp, fp, i32, i32, i32, f32, f32, i32, i32, fp, fp, i32, fp]),
     'asr_masked_mean': (i32, [fp, fp, i32, i32, i32, fp, fp]),
     'asr_masked_mean_tanh_bwd': (i32, [fp, fp, fp, i32, i32, i32, fp, fp]),
     'asr_seq_pool_fwd': (i32, [fp, sz, sz, fp, i32, i32, i32, i32, fp, fp]),

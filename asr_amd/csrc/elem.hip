@@ -421,6 +421,60 @@ extern "C" int asr_affine_rows(const float* x, int ldx, const float* a, const fl
     return ASR_OK;
 }
 
+// The (B,F) algebra of the inter / intra variance costs of scripts/hypernets/exp_prj_hyper.py:108-124 on per-sequence
+// statistics st = [mu ; S0 ; S2] (masked mean, plain sum and sum of squares over time of one direction's inner
+// hidden sequence, each (Bg, F)):  inter = -0.5 mean_f var_b(mu),  intra = 0.5 mean_{b,f} (S2 - 2 mu S0 + T mu^2) / len_b,
+// and the coefficients (a, c0, c1) with which asr_affine_rows turns the sequence into the gradient of
+// w_inter * inter + w_intra * intra for the rows [b0, b0 + Bloc) of this process (tpad: per-row count of frames the
+// sums ran over when the rows come from shards with different padding, else T).  One workgroup; sums in double, in a
+// fixed order.
+__global__ __launch_bounds__(256) void var_costs_kernel(const float* __restrict__ st, const float* __restrict__ len,
+                                                         const float* __restrict__ tpad, int Bg, int F, int T, float w_inter, float w_intra, int b0,
+                                                         int Bloc, float* __restrict__ coef, float* __restrict__ costs,
+                                                         int accumulate) {
+    __shared__ double red[2][256];
+    const float* mu = st; const float* S0 = st + (size_t)Bg * F; const float* S2 = st + (size_t)2 * Bg * F;
+    double acc_inter = 0.0, acc_intra = 0.0;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        double sm = 0.0;
+        for (int b = 0; b < Bg; ++b) sm += (double)mu[(size_t)b * F + f];
+        const double mbar = sm / Bg;
+        double var = 0.0;
+        for (int b = 0; b < Bg; ++b) {
+            const double m = (double)mu[(size_t)b * F + f], L = (double)len[b];
+            const double Tb = tpad ? (double)tpad[b] : (double)T;          // frames the sums of row b ran over
+            const double s0 = (double)S0[(size_t)b * F + f], s2 = (double)S2[(size_t)b * F + f];
+            var += (m - mbar) * (m - mbar);
+            acc_intra += (s2 - 2.0 * m * s0 + Tb * m * m) / L;
+            const int bl = b - b0;
+            if (coef && bl >= 0 && bl < Bloc) {
+                const double a = ((double)w_intra / ((double)Bg * F)) / L;
+                coef[((size_t)0 * Bloc + bl) * F + f] = (float)a;
+                coef[((size_t)1 * Bloc + bl) * F + f] = (float)(-a * m);
+                coef[((size_t)2 * Bloc + bl) * F + f] = (float)(-(double)w_intra * (s0 - Tb * m) / ((double)Bg * F * L * L)
+                                                                - (double)w_inter * (m - mbar) / ((double)F * Bg * L));
+            }
+        }
+        acc_inter += var / Bg;
+    }
+    red[0][threadIdx.x] = acc_inter; red[1][threadIdx.x] = acc_intra;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double s_ = 0.0;
+        for (int i = 0; i < 256; ++i) s_ += red[threadIdx.x][i];
+        const float v = threadIdx.x == 0 ? (float)(-0.5 * s_ / F) : (float)(0.5 * s_ / ((double)Bg * F));
+        costs[threadIdx.x] = accumulate ? costs[threadIdx.x] + v : v;
+    }
+}
+extern "C" int asr_var_costs(const float* st, const float* len, const float* tpad, int Bg, int F, int T, float w_inter, float w_intra,
+                             int b0, int Bloc, float* coef, float* costs, int accumulate, hipStream_t stream) {
+    if (!st || !len || !costs || Bg <= 0 || F <= 0 || T <= 0 || b0 < 0 || Bloc < 0 || b0 + Bloc > Bg) return ASR_ERR_ARG;
+    hipLaunchKernelGGL(var_costs_kernel, dim3(1), dim3(256), 0, stream, st, len, tpad, Bg, F, T, w_inter, w_intra, b0, Bloc,
+                       coef, costs, accumulate);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
 // rows are (t,b) time-major: y[r, :] = x[r, :] * s[r % B, :] (s optionally passed through relu)
 // LHUC epilogue (libs/lhuclstm_layers.py:461-462) and its gradient wrt the hidden sequence.
 __global__ void rowscale_kernel(const float* x, int ldx, const float* s, int B, int relu, float* y,

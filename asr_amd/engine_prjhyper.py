@@ -76,38 +76,49 @@ class PrjHyperPair(object):
 
     def aux_costs(self, w_inter=0.0, w_intra=0.0):
         """scripts/hypernets/exp_prj_hyper.py:108-124 on the inner hidden sequences of the last forward:
-        returns (train_inter_cost, train_intra_cost); with a non-zero weight the gradient of
+        returns a device tensor (train_inter_cost, train_intra_cost); with a non-zero weight the gradient of
         w_inter*inter + w_intra*intra with respect to those sequences is left for the next backward.
-        Per-row sums on the device (masked mean: asr_seq_pool_fwd mode 2; unmasked sum and sum of squares over
-        time: asr_colreduce with gmod = B), the (B,F) algebra on the host, the gradient by asr_affine_rows."""
+        Everything on the device: per-row statistics (masked mean: asr_seq_pool_fwd mode 2; unmasked sum and sum of
+        squares over time: asr_colreduce with gmod = B), the (B,F) algebra and both costs by asr_var_costs, the
+        gradient by asr_affine_rows.  Data parallel: the costs are statistics of the GLOBAL batch, so the ranks
+        all-gather their (3,B,F) statistics, lengths and padded T (each rank keeps the padding of its own shard) and
+        every rank forms the global costs and the coefficients of its own rows."""
         ctx = self.ctx; T, B, mask = ctx['T'], ctx['B'], ctx['mask']
         F = self.F; rows = T * B
+        world = getattr(self.net, 'world', 1)
+        rank = getattr(self.net, 'dropout_rank', 0) if world > 1 else 0
+        want = (w_inter != 0.0) or (w_intra != 0.0)
         st = self._buf('aux_st', 3 * self.ndir * B, F)
+        lens = self._buf('aux_len', 1, B)
+        torch.sum(mask, dim=1, out=lens[0])                       # plumbing: the utterance lengths
+        costs = self._buf('aux_costs', 1, 2)
         for d in range(self.ndir):
             feat = self.inner_hid(d)                                  # (rows, F) view, leading dimension 2F
             o = 3 * d * B
             ops.seq_pool_fwd(feat, 2 * F, B * 2 * F, mask.contiguous(), B, T, F, 2, st[o:o + B])
             ops.colreduce(feat, st[o + B:o + 2 * B], rows, F, gmod=B, ldx=2 * F)
             ops.colreduce(feat, st[o + 2 * B:o + 3 * B], rows, F, y=feat, gmod=B, ldx=2 * F, ldy=2 * F)
-        h = st.detach().cpu().numpy().astype(np.float64).reshape(self.ndir, 3, B, F)
-        L = mask.sum(1).cpu().numpy().astype(np.float64)[:, None]
-        inter = 0.0; intra = 0.0
-        want = (w_inter != 0.0) or (w_intra != 0.0)
-        if want and getattr(self.net, 'world', 1) > 1:
-            raise NotImplementedError('asr_amd: the inter / intra costs are batch statistics of one process')
+        Bg, b0, stg, leng, tpad = B, 0, st, lens[0], None
+        if world > 1:
+            import torch.distributed as dist
+            Bg, b0 = B * world, B * rank
+            parts = [torch.empty_like(st) for _ in range(world)]
+            dist.all_gather(parts, st)                                # (world) x (ndir, 3, B, F)
+            stg = torch.stack([p_.view(self.ndir, 3, B, F) for p_ in parts], 2).reshape(self.ndir * 3 * Bg, F).contiguous()
+            meta = torch.cat([lens[0], torch.full((B,), float(T), device=st.device)])
+            metas = [torch.empty_like(meta) for _ in range(world)]
+            dist.all_gather(metas, meta)
+            leng = torch.cat([m_[:B] for m_ in metas]).contiguous()
+            tpad = torch.cat([m_[B:] for m_ in metas]).contiguous()
         for d in range(self.ndir):
-            mu, S0, S2 = h[d]
-            seq_var = (S2 - 2.0 * mu * S0 + T * mu * mu) / L
-            inter += -0.5 * float(np.mean(mu.var(0))); intra += 0.5 * float(np.mean(seq_var))
+            coef = self._buf('aux_coef%d' % d, 3 * B, F) if want else None
+            ops.var_costs(stg[3 * d * Bg:3 * (d + 1) * Bg], leng, tpad, Bg, F, T, float(w_inter), float(w_intra), b0, B,
+                          coef, costs, accumulate=d > 0)
             if want:
-                a = (w_intra / (B * F)) / L * np.ones_like(mu)
-                c0 = -a * mu
-                c1 = -w_intra * (S0 - T * mu) / (B * F * L * L) - w_inter * (mu - mu.mean(0)) / (F * B * L)
-                co = torch.from_numpy(np.stack([a, c0, c1]).astype(np.float32)).to(st.device)
                 g = self._buf('aux_g%d' % d, rows, F)
-                ops.affine_rows(self.inner_hid(d), 2 * F, co[0], co[1], co[2], mask, B, g, F, rows, F)
+                ops.affine_rows(self.inner_hid(d), 2 * F, coef[:B], coef[B:2 * B], coef[2 * B:], mask, B, g, F, rows, F)
                 self.inner_grad[d] = g
-        return inter, intra
+        return costs[0]
 
     _SAVE = (('gi', 4), ('go', 4), ('ci', 1), ('co', 1), ('ri', 1), ('ro', 1), ('xhi', 1), ('xho', 1), ('sc', 12), ('a', 4))
     _BWD = (('dii', 4), ('doi', 4), ('dsc', 12), ('da', 4), ('douti', 1), ('douto', 1))

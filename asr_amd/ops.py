@@ -118,6 +118,11 @@ def dropout(x, y, rows, n, p, seed, stream_id):
     return y
 
 
+def var_costs(st, lens, tpad, Bg, F, T, w_inter, w_intra, b0, Bloc, coef, costs, accumulate):
+    check(_lib.lib().asr_var_costs(_p(st), _p(lens), _p(tpad), Bg, F, T, w_inter, w_intra, b0, Bloc, _p(coef), _p(costs),
+                                   int(accumulate), _s()), 'asr_var_costs')
+
+
 def affine_rows(x, ldx, a, c0, c1, mask, B, y, ldy, rows, n):
     check(_lib.lib().asr_affine_rows(_p(x), ldx, _p(a), _p(c0), _p(c1), _p(mask), mask.stride(0), mask.stride(1), B,
                                      _p(y), ldy, rows, n, _s()), 'asr_affine_rows')

@@ -102,15 +102,15 @@ def build_prj_hyper_trainer(input_data, input_mask, target_data, target_mask, ne
         ym = _dev(network, ymask, f32)
         ce, ok, _ = network.loss(_dev(network, x, f32), _dev(network, mask, f32), _dev(network, y, torch.int32),
                                  ym, cond=None, train=True)
-        inter, intra = pair.aux_costs(float(inter_weight), float(intra_weight))
+        costs = pair.aux_costs(float(inter_weight), float(intra_weight))       # device tensor (inter, intra)
         network.backward()
         red.finish()
         red.agree_on_status()
         gn = update.apply(network, want_sqrt=True)
-        out = torch.cat([ce, ok, gn, ym.sum().reshape(1)]).cpu().numpy()
+        out = torch.cat([ce, ok, gn, ym.sum().reshape(1), costs]).cpu().numpy()
         nfr = max(float(out[3]), 1.0)
-        return [np.float32(out[0] / nfr), np.float32(out[1] / nfr), np.float32(out[2]), np.float32(inter),
-                np.float32(intra)]
+        return [np.float32(out[0] / nfr), np.float32(out[1] / nfr), np.float32(out[2]), np.float32(out[4]),
+                np.float32(out[5])]
 
     return training_fn, updater_params
 

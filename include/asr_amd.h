@@ -100,6 +100,12 @@ int asr_dropout(const float* x, int ldx, float* y, int ldy, int rows, int n, flo
 int asr_affine_rows(const float* x, int ldx, const float* a, const float* c0, const float* c1, const float* mask,
                     int mask_stride_b, int mask_stride_t, int B, float* y, int ldy, int rows, int n,
                     asr_stream_t stream);
+/* The (B,F) algebra of the same costs: st = [mu ; S0 ; S2] (masked mean, sum and sum of squares over time, each
+ * (Bg,F)) and the sequence lengths -> costs[0] = inter, costs[1] = intra (added to what is there if accumulate), and,
+ * if coef != NULL, the (a, c0, c1) of asr_affine_rows for the batch rows [b0, b0+Bloc) of this process, each (Bloc,F).
+ * tpad (or NULL = T for every row): frames the sums of each row ran over, for rows gathered from shards padded apart. */
+int asr_var_costs(const float* st, const float* len, const float* tpad, int Bg, int F, int T, float w_inter, float w_intra, int b0,
+                  int Bloc, float* coef, float* costs, int accumulate, asr_stream_t stream);
 int asr_masked_mean(const float* x, const float* mask, int B, int T, int F, float* out,
                     asr_stream_t stream);
 int asr_masked_mean_tanh_bwd(const float* ds, const float* mask, const float* pre, int B, int T, int F,

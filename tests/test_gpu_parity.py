@@ -418,7 +418,7 @@ def test_projection_hyper_aux_costs_and_trainer():
     onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
     oc, os_, opred, ograds = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], aux=(0.7, 1.3))
     net.loss(x, m, y, m, None, train=True)
-    inter, intra = fi.pair.aux_costs(0.7, 1.3)
+    inter, intra = fi.pair.aux_costs(0.7, 1.3).tolist()        # a device tensor: nothing of the algebra runs on the host
     net.backward()
     net.check_status()
     assert abs(inter - onet.aux_costs[0]) < 1e-5 * max(1.0, abs(onet.aux_costs[0]))

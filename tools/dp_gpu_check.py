@@ -39,6 +39,30 @@ for name, mk in (('hyper', lambda: build_deep_hyperlstm('h', None, None, 5, 2, 8
         worst = max(worst, float(np.max(np.abs(a - r)) / (np.max(np.abs(r)) + 1e-3 * gmax)))
     print('rank %d %s: worst relative gradient difference %.2e' % (rank, name, worst), flush=True)
     ok = ok and worst < 2e-5
+# the inter / intra variance costs of scripts/hypernets/exp_prj_hyper.py are statistics of the GLOBAL batch: the ranks
+# gather their per-sequence statistics (engine_prjhyper.PrjHyperPair.aux_costs).  Equal lengths, so that the padded
+# frames the reference's unmasked sums run over are the same in both runs.
+from asr_amd.gating_hyper_nets import deep_projection_hyper_model
+mkp = lambda: deep_projection_hyper_model(None, None, 5, 6, 2, 4, 8, grad_clipping=1.0, device=dev, seed=9)
+b = make_batch(np.random.default_rng(11), 4, 9, 5, 6)
+b['mask'][:] = 1.0
+full = (b['x'], b['mask'], None, None, b['y'], b['mask'])
+ref, fi, _ = mkp()
+ref.loss(t(full[0]), t(full[1]), t(full[4]), t(full[5]), None, train=True)
+c_ref = fi.pair.aux_costs(0.7, 1.3).tolist()
+ref.backward(); torch.cuda.synchronize()
+g_ref = [g.copy() for g in ref.get_all_grad_values()]
+net, fi, _ = mkp()
+ar = dp.GradAllReduce(net)
+sh = dp.shard_batch(full, rank, world)
+net.loss(t(sh[0]), t(sh[1]), t(sh[4]), t(sh[5]), None, train=True)
+c_dp = fi.pair.aux_costs(0.7, 1.3).tolist()
+net.backward(); ar.finish(); torch.cuda.synchronize(); net.check_status()
+gmax = max(np.max(np.abs(g)) for g in g_ref)
+worst = max(float(np.max(np.abs(a - r)) / (np.max(np.abs(r)) + 1e-3 * gmax)) for a, r in zip(net.get_all_grad_values(), g_ref))
+dc = max(abs(a - r) / max(1.0, abs(r)) for a, r in zip(c_dp, c_ref))
+print('rank %d prjhyper + variance costs: worst relative gradient difference %.2e, costs %.2e' % (rank, worst, dc), flush=True)
+ok = ok and worst < 2e-5 and dc < 1e-5
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
