@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
 // the second resident workgroup per CU (118 TFLOP/s).
 // LDS images per operand and split part, chosen by the operand's storage order so that both the global
 // loads and the LDS stores are 16-byte / conflict-free:
-//   k contiguous in memory ([row][k]):  [k / 8][row][k % 8] bf16, written 8 B per lane, read ds_read_b128
+//   k contiguous in memory ([row][k]):  [k / 8][row][k % 8] bf16 (k halves 64 B apart in bank space), written 8 B per
+//                                        lane, read ds_read_b128
 //   row contiguous in memory ([k][row]): [k][row] bf16 with 320-byte k rows, written 8 B per lane (4 rows of one
 //                                        k), read with the transposing ds_read_b64_tr_b16 (4 k x 16 rows per
 //                                        16-lane group): two reads give a lane the 8 k of its row
@@ -241,7 +242,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define SPL_KROW 320                      // bytes per k row of the row-contiguous image: 128 bf16 + 64 B, so that the
                                           // 4 k rows x 2 column groups of a transposed read fall on 64 distinct banks
-#define SPL_IMG (16 * SPL_KROW)           // bytes per image (>= 2 * 128 * 16 of the other layout)
+#define SPL_IMG (16 * SPL_KROW)           // bytes per image (>= 2 * SPL_KHALF of the other layout)
+#define SPL_KHALF (128 * 16 + 64)         // bytes per k half of the k-contiguous image: + 16 banks, so that the two
+                                          // k halves a 16-lane group of ds_write_b64 touches do not share banks
 
 // two fp32 values -> packed bf16 pairs of their split parts (one v_cvt_pk_bf16_f32 per part)
 template <int NP>
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
             const int idx = e * 256 + tid;
             // [k][row] storage: 4 rows c4.. of k = 2 kp + e;   [row][k] storage: row idx / 4, k = 4 (idx % 4) ..
             const size_t off = kmaj ? (size_t)(2 * kp + e) * SPL_KROW + c4 * 2
-                                    : ((size_t)(((idx % 4) * 4) >> 3) * 128 + idx / 4) * 16 + (((idx % 4) * 4) & 7) * 2;
+                                    : (size_t)(((idx % 4) * 4) >> 3) * SPL_KHALF + (idx / 4) * 16 + (((idx % 4) * 4) & 7) * 2;
 #pragma unroll
             for (int p = 0; p < NP; ++p) *(u32x2*)(img[p] + off) = u32x2{w0[p], w1[p]};
         }
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * SPL_KROW));
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
-        return *(const bf16x8*)(img + ((size_t)lk * 128 + row0 + lr) * 16);
+        return *(const bf16x8*)(img + (size_t)lk * SPL_KHALF + (row0 + lr) * 16);
     };
 #define SPL_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc_, 0, 0, 0)
     auto mfma_tile = [&](int tile) {
