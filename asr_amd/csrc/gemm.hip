@@ -387,7 +387,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
             // cell integration far better than rounding noise.  So the TERMS products of a K-tile form a chain from a
             // zero accumulator and join the running sum with a round-to-nearest v_fma_f32, and K-tiles alternate in
             // sign: odd tiles multiply -A (the split of -x is exactly minus the split of x) and are subtracted, so the
-            // truncation pushes the sum down on even tiles and up on odd ones and cancels in expectation.
+            // truncation pushes the sum down on even tiles and up on odd ones and cancels in expectation.  (Accumulating
+            // straight into the running sum and flipping ITS sign every 4 tiles instead saves the 64 joins per tile: rms
+            // error 1.7e-7 instead of 8.6e-8, bias -3e-9, 2.5 % faster: not taken.)
             constexpr int pa[8] = {0, 0, 1, 1, 0, 2, 1, 2}, pb[8] = {0, 1, 0, 1, 2, 0, 2, 1};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
