@@ -49,6 +49,19 @@ class PrjHyperDesc(C.Structure):
                 ('dir', PrjHyperDir * 2)]
 
 
+class ScalingDir(C.Structure):
+    _fields_ = [('reverse', i32)] + [(n, fp) for n in (
+        'inner_in', 'outer_in', 'Wio', 'S', 's', 'Woo', 'wpeep', 'lna_i', 'lnb_i', 'lna_o', 'lnb_o', 'init', 'hid',
+        'gi', 'go', 'ci', 'co', 'xh_i', 'xh_o', 'rs_i', 'rs_o', 'sc', 'a',
+        'dhid', 'dgi', 'dgo', 'dsc', 'da', 'dh', 'dy_i', 'dy_o', 'dpeep', 'dinit')]
+
+
+class ScalingDesc(C.Structure):
+    _fields_ = [('T', i32), ('B', i32), ('N', i32), ('H', i32), ('ndir', i32), ('b0', i32), ('Btot', i32),
+                ('use_peepholes', i32), ('use_layer_norm', i32), ('grad_clip', f32), ('mask', fp),
+                ('mask_stride_b', i32), ('mask_stride_t', i32), ('dir', ScalingDir * 2)]
+
+
 class HyperScanDesc(C.Structure):
     _fields_ = [('T', i32), ('B', i32), ('N', i32), ('H', i32), ('ndir', i32), ('step0', i32), ('step1', i32),
                 ('grad_clip', f32), ('clip_outcell', i32), ('lhuc_reparam', i32), ('mask', fp), ('mask_stride_b', i32), ('mask_stride_t', i32),
@@ -84,6 +97,9 @@ _SIGS = {
     'asr_prjhyper_ws_bytes': (sz, [i32, i32, i32, i32]),
     'asr_prjhyper_fwd': (i32, [C.POINTER(PrjHyperDesc), fp, sz, fp]),
     'asr_prjhyper_bwd': (i32, [C.POINTER(PrjHyperDesc), fp, sz, fp]),
+    'asr_scaling_ws_bytes': (sz, [i32, i32, i32, i32]),
+    'asr_scaling_fwd': (i32, [C.POINTER(ScalingDesc), fp, sz, fp]),
+    'asr_scaling_bwd': (i32, [C.POINTER(ScalingDesc), fp, sz, fp]),
     'asr_opt_step': (i32, [i32, fp, fp, fp, fp, sz, f32, f32, f32, f32, fp, fp]),
     'asr_norm_clip_mult': (i32, [fp, f32, f32, fp, fp]),
     'asr_lstm_pack_floats': (sz, [i32, i32]),

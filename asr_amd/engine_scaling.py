@@ -181,3 +181,231 @@ class ScalingPair(object):
             gM = dp.g('M')
             ops.gemm(Hh, dD, gM[:H], ta=True)
             ops.colreduce(c['dcv'], gM[H], c['dcv'].shape[0], 12 * N)
+
+
+# ------------------------------------------------------------------------------------------------
+# The layer with its options (use_peepholes / use_layer_norm / learn_init): step-loop path
+# ------------------------------------------------------------------------------------------------
+_LN5 = G4 + ('outcell',)
+_MAPS = ('in', 'hid', 'bias', 'cell')          # column-block order of S / s
+
+
+def _mk_scaling_step(store, prefix, D, N, H, peep, ln, learn_init):
+    """Engine tensors (gate-major, as asr_scaling_dir wants them) and the reference parameters as views of them, in
+    the add_param order of specs.scaling_hyper_params.  Blocks the reference keeps as non-trainable zero constants
+    (the cell gate's peephole and scale_outer_cell blocks) exist in the engine tensors, start at zero and receive
+    zero gradients."""
+    import ctypes  # noqa: F401  (kept local: this module is imported by builders that never take this path)
+    NS = 4 if peep else 3
+    dp = DirParams(store, prefix)
+    dp.add('Wix', (D, 4 * H)); dp.add('Wio', (H + N, 4 * H)); dp.add('bi', (4 * H,))
+    if peep:
+        dp.add('wpeep', (4 * H,))
+    if ln:
+        dp.add('lna_i', (5, H)); dp.add('lnb_i', (5, H))
+    if learn_init:
+        dp.add('init', (2 * H + 2 * N,))
+    dp.add('Wox', (D, 4 * N)); dp.add('Woo', (N, 4 * N)); dp.add('S', (H, NS * 4 * N)); dp.add('s', (NS * 4 * N,))
+    if ln:
+        dp.add('lna_o', (5, N)); dp.add('lnb_o', (5, N))
+    cb = lambda k, U: (lambda E: E[:, k * U:(k + 1) * U])
+    rcb = lambda r0, r1, k, U: (lambda E: E[r0:r1, k * U:(k + 1) * U])
+    vb = lambda k, U: (lambda E: E[k * U:(k + 1) * U])
+    row = lambda k: (lambda E: E[k])
+    seg = lambda a, b: (lambda E: E[a:b].view(1, b - a))
+    table = {}
+    for g, gn in enumerate(G4):
+        table['W_inner_in_to_inner_' + gn] = ('Wix', cb(g, H))
+        table['W_inner_hid_to_inner_' + gn] = ('Wio', rcb(0, H, g, H))
+        table['W_outer_hid_to_inner_' + gn] = ('Wio', rcb(H, H + N, g, H))
+        table['W_inner_cell_to_inner_' + gn] = ('wpeep', vb(g, H))
+        table['b_inner_' + gn] = ('bi', vb(g, H))
+        table['W_outer_in_to_outer_' + gn] = ('Wox', cb(g, N))
+        table['W_outer_hid_to_outer_' + gn] = ('Woo', cb(g, N))
+        for m, mn in enumerate(_MAPS):
+            table['W_inner_hid_to_outer_%s_%s' % (mn, gn)] = ('S', cb(4 * m + g, N))
+            table['b_inner_hid_to_outer_%s_%s' % (mn, gn)] = ('s', vb(4 * m + g, N))
+    for k, gn in enumerate(_LN5):
+        table['W_inner_ln_' + gn] = ('lna_i', row(k)); table['b_inner_ln_' + gn] = ('lnb_i', row(k))
+        table['W_outer_ln_' + gn] = ('lna_o', row(k)); table['b_outer_ln_' + gn] = ('lnb_o', row(k))
+    table.update(inner_cell_init=('init', seg(0, H)), inner_hid_init=('init', seg(H, 2 * H)),
+                 outer_cell_init=('init', seg(2 * H, 2 * H + N)), outer_hid_init=('init', seg(2 * H + N, 2 * H + 2 * N)))
+    for name, _, _ in specs.scaling_hyper_params(D, H, N, peep, ln, learn_init):
+        key, fn = table[name]
+        dp.map(name, key, 'fn', fn)
+    return dp
+
+
+class ScalingStepPair(object):
+    """ScalingHyperLSTMLayer pair with any of use_peepholes / use_layer_norm / learn_init, on asr_scaling_fwd/bwd
+    (asr_amd/csrc/step_scaling.hip).  Host side as for ProjectionHyperLSTMLayer: the two all-timestep input
+    projections before the loop, dX and every parameter gradient as GEMMs / column reductions over all T after it.
+    Gate-major layout throughout (no interleave, no padding of the inner width beyond % 4)."""
+    kind = 'scaling'
+    stateful = False
+
+    def __init__(self, net, idx, D, N, H, clip, ndir, use_peepholes, use_layer_norm, learn_init):
+        if N % 4 or H % 4:
+            raise ValueError('asr_amd: ScalingHyperLSTMLayer with options needs both unit counts divisible by 4')
+        self.net = net; self.idx = idx
+        self.D, self.N, self.H = D, N, H
+        self.peep, self.ln, self.learn_init = bool(use_peepholes), bool(use_layer_norm), bool(learn_init)
+        self.NS = 4 if self.peep else 3
+        self.clip = float(clip); self.ndir = ndir
+        self.out_dim = ndir * N
+        self.dirs = [_mk_scaling_step(net.store, 'L%d.%d.' % (idx, d), D, N, H, self.peep, self.ln, self.learn_init)
+                     for d in range(ndir)]
+        self.reverse = [False, True][:ndir]
+        self.inner_grad = [None] * ndir
+
+    def describe(self):
+        out = {}
+        for d, nm in enumerate(('fwd', 'bwd')):
+            if d >= self.ndir:
+                out[nm] = None
+                continue
+            out[nm] = dict(kind='scaling',
+                           args=dict(num_inner_units=self.H, num_outer_units=self.N, grad_clipping=self.clip,
+                                     backwards=self.reverse[d], use_peepholes=self.peep, use_layer_norm=self.ln,
+                                     learn_init=self.learn_init),
+                           params=[r[0] for r in self.dirs[d].refmap])
+        return out
+
+    def _buf(self, name, rows, cols):
+        return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols)
+
+    def inner_hid(self, d):
+        return self.ctx['d'][d]['hid'][:, :self.H]
+
+    def _fwd_bufs(self):
+        N, H = self.N, self.H
+        b = [('hid', H + N), ('gi', 4 * H), ('go', 4 * N), ('ci', H), ('co', N), ('sc', self.NS * 4 * N), ('a', 4 * N)]
+        if self.ln:
+            b += [('xh_i', 5 * H), ('xh_o', 5 * N), ('rs_i', 5), ('rs_o', 5)]
+        return b
+
+    def _bwd_bufs(self):
+        N, H = self.N, self.H
+        b = [('dh', H + N), ('dgi', 4 * H), ('dgo', 4 * N), ('dsc', self.NS * 4 * N), ('da', 4 * N)]
+        if self.ln:
+            b += [('dy_i', 5 * H), ('dy_o', 5 * N)]
+        if self.peep:
+            b += [('dpeep', 3 * H)]
+        return b
+
+    def _desc(self, T, B, mask, backward):
+        desc = _lib.ScalingDesc()
+        desc.T, desc.N, desc.H, desc.ndir, desc.Btot = T, self.N, self.H, self.ndir, B
+        desc.use_peepholes, desc.use_layer_norm = int(self.peep), int(self.ln)
+        desc.grad_clip = self.clip
+        desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
+        for d, dp in enumerate(self.dirs):
+            c = self.ctx['d'][d]
+            Dd = desc.dir[d]
+            Dd.reverse = 1 if self.reverse[d] else 0
+            for f, key in (('Wio', 'Wio'), ('S', 'S'), ('s', 's'), ('Woo', 'Woo'), ('wpeep', 'wpeep'), ('lna_i', 'lna_i'),
+                           ('lnb_i', 'lnb_i'), ('lna_o', 'lna_o'), ('lnb_o', 'lnb_o'), ('init', 'init')):
+                if dp.has(key):
+                    setattr(Dd, f, dp.p(key).data_ptr())
+            for f in ('inner_in', 'outer_in') + tuple(n for n, _ in self._fwd_bufs()):
+                setattr(Dd, f, c[f].data_ptr())
+            if backward:
+                for f in ('dhid',) + tuple(n for n, _ in self._bwd_bufs()):
+                    setattr(Dd, f, c[f].data_ptr())
+                if self.learn_init:
+                    Dd.dinit = c['dinit'].data_ptr()
+        return desc
+
+    def _run(self, desc, B, backward):
+        import ctypes as C
+        L = _lib.lib()
+        need = L.asr_scaling_ws_bytes(min(B, 16), self.N, self.H, self.ndir)
+        ws = self.net._workspace(('scaling', self.idx), need)
+        fn = L.asr_scaling_bwd if backward else L.asr_scaling_fwd
+        for b0 in range(0, B, 16):                      # batch rows are independent: chunks of <= 16 rows
+            desc.b0 = b0; desc.B = min(16, B - b0)
+            check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                  'asr_scaling_%s' % ('bwd' if backward else 'fwd'))
+
+    def forward(self, X, T, B, mask, cond, train):
+        N, H = self.N, self.H
+        rows = T * B
+        Y = self._buf('Y', rows, self.out_dim)
+        self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[])
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            c['inner_in'] = ops.gemm(X, dp.p('Wix'), self._buf('iin%d' % d, rows, 4 * H), bias=dp.p('bi'))
+            c['outer_in'] = ops.gemm(X, dp.p('Wox'), self._buf('oin%d' % d, rows, 4 * N))
+            for nm, w in self._fwd_bufs():
+                c[nm] = self._buf('%s%d' % (nm, d), rows, w)
+            ctx['d'].append(c)
+        self._run(self._desc(T, B, mask, False), B, False)
+        for d in range(self.ndir):                      # SliceLayer(num_inner_units:) + ConcatLayer
+            Y[:, d * N:(d + 1) * N].copy_(ctx['d'][d]['hid'][:, H:])
+        return Y
+
+    def backward(self, dY, need_dx=True):
+        net = self.net; ctx = self.ctx; N, H = self.N, self.H
+        X, T, B, mask = ctx['X'], ctx['T'], ctx['B'], ctx['mask']
+        rows = T * B
+        for d in range(self.ndir):
+            c = ctx['d'][d]
+            c['dhid'] = self._buf('dhid%d' % d, rows, H + N)
+            if self.inner_grad[d] is None:
+                c['dhid'][:, :H].zero_()
+            else:
+                c['dhid'][:, :H].copy_(self.inner_grad[d]); self.inner_grad[d] = None
+            c['dhid'][:, H:].copy_(dY[:, d * N:(d + 1) * N])
+            for nm, w in self._bwd_bufs():
+                c[nm] = self._buf('%s%d' % (nm, d), rows, w)
+            if self.learn_init:
+                c['dinit'] = self._buf('dinit%d' % d, B, 2 * H + 2 * N)
+        self._run(self._desc(T, B, mask, True), B, True)
+        dX = self._buf('dX', rows, self.D) if need_dx else None
+        if need_dx:
+            for d, dp in enumerate(self.dirs):
+                c = ctx['d'][d]
+                ops.gemm(c['dgi'], dp.p('Wix'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+                ops.gemm(c['dgo'], dp.p('Wox'), dX, tb=True, beta=1.0)
+        with net.deferred():
+            self._param_grads(ctx, rows, T, B)
+        return dX
+
+    def _param_grads(self, ctx, rows, T, B):
+        N, H = self.N, self.H
+        X = ctx['X']
+        n1 = (T - 1) * B
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            hid = c['hid']
+            if not self.reverse[d]:
+                sl_prev, sl_cur, sl_first = slice(0, n1), slice(B, rows), slice(0, B)
+            else:
+                sl_prev, sl_cur, sl_first = slice(B, rows), slice(0, n1), slice(n1, rows)
+            ops.gemm(X, c['dgi'], dp.g('Wix'), ta=True)
+            ops.colreduce(c['dgi'], dp.g('bi'), rows, 4 * H)
+            ops.gemm(X, c['dgo'], dp.g('Wox'), ta=True)
+            if n1:
+                ops.gemm(hid[sl_prev], c['dgi'][sl_cur], dp.g('Wio'), ta=True)
+                ops.gemm(hid[sl_prev][:, H:], c['da'][sl_cur], dp.g('Woo'), ta=True)
+            else:                                       # T == 1: no recurrent step ran
+                dp.g('Wio').zero_(); dp.g('Woo').zero_()
+            if self.learn_init:                         # the first step's "previous hid" is the learned row, not zero
+                ini = dp.p('init')
+                h0 = self._buf('h0_%d' % d, B, H + N)
+                h0[:, :H].copy_(ini[H:2 * H].expand(B, H)); h0[:, H:].copy_(ini[2 * H + N:].expand(B, N))
+                ops.gemm(h0, c['dgi'][sl_first], dp.g('Wio'), ta=True, beta=1.0)
+                ops.gemm(h0[:, H:], c['da'][sl_first], dp.g('Woo'), ta=True, beta=1.0)
+                ops.colreduce(c['dinit'], dp.g('init'), B, 2 * H + 2 * N)
+            ops.gemm(hid[:, :H], c['dsc'], dp.g('S'), ta=True)
+            ops.colreduce(c['dsc'], dp.g('s'), rows, self.NS * 4 * N)
+            if self.peep:
+                gw = dp.g('wpeep')
+                gw.zero_()                              # the cell gate has no peephole (cell_trainable=False)
+                for k, blk in ((0, 0), (1, 1), (2, 3)):
+                    ops.colreduce(c['dpeep'][:, k * H:(k + 1) * H], gw[blk * H:(blk + 1) * H], rows, H, ldx=3 * H)
+            if self.ln:
+                ops.colreduce(c['dy_i'], dp.g('lna_i').view(-1), rows, 5 * H, y=c['xh_i'])
+                ops.colreduce(c['dy_i'], dp.g('lnb_i').view(-1), rows, 5 * H)
+                ops.colreduce(c['dy_o'], dp.g('lna_o').view(-1), rows, 5 * N, y=c['xh_o'])
+                ops.colreduce(c['dy_o'], dp.g('lnb_o').view(-1), rows, 5 * N)

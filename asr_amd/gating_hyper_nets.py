@@ -251,18 +251,21 @@ def deep_scaling_hyper_model(input_var, mask_var, num_inputs, num_outputs, num_i
     OUTER hidden sequences (fwd | bwd) feed the next layer and the SequenceDenseLayer.  With
     get_inner_hid=True the reference returns the inner-hidden slice layers before the output layer;
     here that is a list of (pair, direction) handles with .get_output() -> (T*B, inner) of the last
-    forward, followed by the Network.  Only the reference defaults use_peepholes=False /
-    use_layer_norm=False / learn_init=False are on the HIP path."""
-    if use_peepholes or use_layer_norm or learn_init:
-        raise NotImplementedError('asr_amd: ScalingHyperLSTMLayer with peepholes / layer norm / learn_init '
-                                  'is not implemented')
-    from .engine_scaling import ScalingPair
+    forward, followed by the Network.  The reference defaults (no option) run on the persistent HyperLSTM scan;
+    use_peepholes / use_layer_norm / learn_init (scripts/timit/exp_scalehyper.py uses the last two) run on the
+    step-loop path of asr_amd/csrc/step_scaling.hip."""
+    from .engine_scaling import ScalingPair, ScalingStepPair
+    options = bool(use_peepholes or use_layer_norm or learn_init)
     net = Network(device or 'cuda:0')
     D = num_inputs
     inner = []
     for H, N in zip(num_inner_units_list, num_outer_units_list):
-        pair = ScalingPair(net, len(net.pairs), D, N, H, grad_clipping or 0, 2)
-        net.add_pair(pair, [specs.scaling_hyper_params(D, H, N)] * 2)
+        if options:        # per-gate layer norms do not fit the persistent scan: the step-loop path (step_scaling.hip)
+            pair = ScalingStepPair(net, len(net.pairs), D, N, H, grad_clipping or 0, 2, use_peepholes, use_layer_norm,
+                                   learn_init)
+        else:
+            pair = ScalingPair(net, len(net.pairs), D, N, H, grad_clipping or 0, 2)
+        net.add_pair(pair, [specs.scaling_hyper_params(D, H, N, use_peepholes, use_layer_norm, learn_init)] * 2)
         inner += [InnerHidHandle(pair, d) for d in range(2)]
         D = pair.out_dim
     net.set_output(D, num_outputs, 'softmax' if use_softmax else 'logits')

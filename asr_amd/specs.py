@@ -197,25 +197,42 @@ def rec_params(cls, D, N, num_factors=None, num_prjs=None, cond_dim=0):
     return out
 
 
-def scaling_hyper_params(D, H, N):
-    """ScalingHyperLSTMLayer, libs/lasagne_libs/hyper_layers.py:570-834, TRAINABLE parameters with
-    use_peepholes=False / use_layer_norm=False (the peephole vectors, the scale_outer_cell map and all
-    layer-norm vectors are then registered with trainable=False, :585-588,:602-609,:716-723,:736-743,
-    and stay out of get_all_params(trainable=True)).  The reference gives each scale bias the NAME of
-    its weight ("W_inner_hid_to_outer_in_<gate>" twice, :694-700); names only label entries here, so
-    the biases are called b_inner_hid_to_outer_* after the attributes they are bound to (:746-757)."""
+def scaling_hyper_params(D, H, N, use_peepholes=False, use_layer_norm=False, learn_init=False):
+    """ScalingHyperLSTMLayer, libs/lasagne_libs/hyper_layers.py:570-834, TRAINABLE parameters in add_param order.
+    Without an option its parameters are registered with trainable=False (:585-588,:602-609,:716-723,:736-743,
+    :669-680,:823-834) and stay out of get_all_params(trainable=True): peephole vectors of the inner cell and the
+    scale_outer_cell map (use_peepholes; never for the cell gate), the per-gate and out-cell layer-norm vectors
+    (use_layer_norm), the four initial-state rows (learn_init).  The reference gives each scale bias the NAME of its
+    weight ("W_inner_hid_to_outer_in_<gate>" twice, :694-700); names only label entries here, so the biases are
+    called b_inner_hid_to_outer_* after the attributes they are bound to (:746-757)."""
     out = []
     for g in GATES_REC:
         fb = 1.0 if g == 'forgetgate' else 0.0
-        out += [('W_inner_in_to_inner_' + g, (D, H), 'orthogonal'), ('W_inner_hid_to_inner_' + g, (H, H), 'orthogonal'),
-                ('W_outer_hid_to_inner_' + g, (N, H), 'orthogonal'), ('b_inner_' + g, (H,), ('const', fb))]
+        out += [('W_inner_in_to_inner_' + g, (D, H), 'orthogonal'), ('W_inner_hid_to_inner_' + g, (H, H), 'orthogonal')]
+        if use_peepholes and g != 'cell':
+            out += [('W_inner_cell_to_inner_' + g, (H,), ('uniform', 0.1))]
+        out += [('W_outer_hid_to_inner_' + g, (N, H), 'orthogonal'), ('b_inner_' + g, (H,), ('const', fb))]
+        if use_layer_norm:
+            out += [('W_inner_ln_' + g, (H,), ('const', 1.0)), ('b_inner_ln_' + g, (H,), ('const', 0.0))]
+    if use_layer_norm:
+        out += [('W_inner_ln_outcell', (H,), ('const', 1.0)), ('b_inner_ln_outcell', (H,), ('const', 0.0))]
+    if learn_init:
+        out += [('inner_cell_init', (1, H), ('const', 0.0)), ('inner_hid_init', (1, H), ('const', 0.0))]
     for g in GATES_REC:
         fb = 1.0 if g == 'forgetgate' else 0.0
         out += [('W_outer_in_to_outer_' + g, (D, N), 'orthogonal'),
                 ('W_inner_hid_to_outer_in_' + g, (H, N), ('const', 0.0)), ('b_inner_hid_to_outer_in_' + g, (N,), ('const', 1.0)),
                 ('W_outer_hid_to_outer_' + g, (N, N), 'orthogonal'),
-                ('W_inner_hid_to_outer_hid_' + g, (H, N), ('const', 0.0)), ('b_inner_hid_to_outer_hid_' + g, (N,), ('const', 1.0)),
-                ('W_inner_hid_to_outer_bias_' + g, (H, N), 'orthogonal'), ('b_inner_hid_to_outer_bias_' + g, (N,), ('const', fb))]
+                ('W_inner_hid_to_outer_hid_' + g, (H, N), ('const', 0.0)), ('b_inner_hid_to_outer_hid_' + g, (N,), ('const', 1.0))]
+        if use_peepholes and g != 'cell':
+            out += [('W_inner_hid_to_outer_cell_' + g, (H, N), 'orthogonal'), ('b_inner_hid_to_outer_cell_' + g, (N,), ('const', 1.0))]
+        out += [('W_inner_hid_to_outer_bias_' + g, (H, N), 'orthogonal'), ('b_inner_hid_to_outer_bias_' + g, (N,), ('const', fb))]
+        if use_layer_norm:
+            out += [('W_outer_ln_' + g, (N,), ('const', 1.0)), ('b_outer_ln_' + g, (N,), ('const', 0.0))]
+    if use_layer_norm:
+        out += [('W_outer_ln_outcell', (N,), ('const', 1.0)), ('b_outer_ln_outcell', (N,), ('const', 0.0))]
+    if learn_init:
+        out += [('outer_cell_init', (1, N), ('const', 0.0)), ('outer_hid_init', (1, N), ('const', 0.0))]
     return out
 
 

@@ -295,6 +295,51 @@ size_t asr_prjhyper_ws_bytes(int B, int N, int F, int ndir);
 int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 
+/* ScalingHyperLSTMLayer with use_peepholes / use_layer_norm / learn_init (libs/lasagne_libs/hyper_layers.py:525-1205;
+ * step :963-1095, step_masked :1097-1118, initial rows :1127-1131, scan :1182-1194).  Without options the layer runs on
+ * asr_hyper_scan_* (clip_outcell = 1); per-gate layer norms need five all-unit reductions per cell and step, so this
+ * path is a step loop inside the library like asr_prjhyper_*: one workgroup per (batch row, direction) runs a cell.
+ * Gate vectors gate-major [i|f|c|o]; hid = [inner_hid | outer_hid].  One call handles batch rows [b0, b0+B), B <= 16. */
+typedef struct asr_scaling_dir {
+    int reverse;
+    const float* inner_in;    /* (T,Btot,4H) x.W_inner_in_to_inner + b_inner (:951) */
+    const float* outer_in;    /* (T,Btot,4N) x.W_outer_in_to_outer (:952) */
+    const float* Wio;         /* (H+N,4H) [W_inner_hid_to_inner ; W_outer_hid_to_inner] (:974-975) */
+    const float* S;           /* (H,NS*4N) [to_outer_in | to_outer_hid | to_outer_bias | to_outer_cell], NS = 3 or 4 (:1030-1033) */
+    const float* s;           /* (NS*4N) */
+    const float* Woo;         /* (N,4N) W_outer_hid_to_outer (:1039) */
+    const float* wpeep;       /* (4H) W_inner_cell_to_inner, cell block zero; NULL without peepholes (:977-979,:1006) */
+    const float *lna_i, *lnb_i; /* (5,H) alpha / beta of the layer norms of ingate, forgetgate, cell, outgate, outcell; NULL without LN */
+    const float *lna_o, *lnb_o; /* (5,N) */
+    const float* init;        /* (2H+2N) inner cell | inner hid | outer cell | outer hid initial rows; NULL = zeros */
+    float* hid;               /* (T,Btot,H+N) */
+    float *gi, *go;           /* (T,Btot,4H) / (T,Btot,4N) post-activation gates, saved for BPTT */
+    float *ci, *co;           /* (T,Btot,H) / (T,Btot,N) masked cell state */
+    float *xh_i, *xh_o;       /* (T,Btot,5H) / (T,Btot,5N) normalised values of the five layer norms (LN only) */
+    float *rs_i, *rs_o;       /* (T,Btot,5) rstd (LN only) */
+    float* sc;                /* (T,Btot,NS*4N) scale maps */
+    float* a;                 /* (T,Btot,4N) outer_hid_prev . W_outer_hid_to_outer */
+    const float* dhid;        /* backward: (T,Btot,H+N) dLoss/d hid */
+    float *dgi, *dgo;         /* (T,Btot,4H) d inner gate pre-activations ; (T,Btot,4N) d outer_input */
+    float* dsc;               /* (T,Btot,NS*4N) */
+    float* da;                /* (T,Btot,4N) */
+    float* dh;                /* (T,Btot,H+N) total d hid_t (work) */
+    float *dy_i, *dy_o;       /* (T,Btot,5H) / (T,Btot,5N) clipped gradients at the layer-norm outputs (LN only) */
+    float* dpeep;             /* (T,Btot,3H) d gate * cell of the inner peepholes (i, f, o); NULL without peepholes */
+    float* dinit;             /* (Btot,2H+2N) gradient wrt the initial rows, per batch row; may be NULL */
+} asr_scaling_dir;
+typedef struct asr_scaling_desc {
+    int T, B, N, H, ndir;
+    int b0, Btot;
+    int use_peepholes, use_layer_norm;
+    float grad_clip;
+    const float* mask; int mask_stride_b, mask_stride_t;
+    asr_scaling_dir dir[2];
+} asr_scaling_desc;
+size_t asr_scaling_ws_bytes(int B, int N, int H, int ndir);
+int asr_scaling_fwd(const asr_scaling_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+int asr_scaling_bwd(const asr_scaling_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

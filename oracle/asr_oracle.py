@@ -431,36 +431,79 @@ def hyperlhuc_scan_bwd(dhid, x, fwd_cache, p, spec):
 # p keys: Wi_x (D,4H), Wi_h (H,4H), Wi_o (N,4H), bi (4H); Wo_x (D,4N), Wo_h (N,4N);
 #         S_in, S_hid, S_bias (H,4N) with biases s_in, s_hid, s_bias (4N)
 # --------------------------------------------------------------------------------------------
+def _scal_cell_fwd(g, c_prev, peep, lnp, U, use_ln):
+    """One cell of ScalingHyperLSTMLayer (hyper_layers.py:977-1025 inner, :1042-1091 outer) from the gate
+    pre-activations g (B,4U), gate-major.  peep: (B or 1, 4U) what multiplies the cell state into the gates
+    (vectors for the inner cell, the per-sample scale_outer_cell map for the outer one; the cell gate's block is zero).
+    lnp: (alpha (5,U), beta (5,U)) for ingate, forgetgate, cell, outgate, outcell.  -> c_new, h_new, cache."""
+    sl = lambda v, n: v[:, n * U:(n + 1) * U]
+    pre = [sl(g, k) + c_prev * sl(peep, k) for k in range(3)]
+    lc = [None] * 5
+    if use_ln:
+        for k in range(3):
+            pre[k], lc[k] = ln_fwd(pre[k], lnp[0][k], lnp[1][k])
+    i = _sig(pre[0]); f = _sig(pre[1]); gc = np.tanh(pre[2])
+    c_new = f * c_prev + i * gc
+    po = sl(g, 3) + c_new * sl(peep, 3)
+    oc = c_new
+    if use_ln:
+        po, lc[3] = ln_fwd(po, lnp[0][3], lnp[1][3])
+        oc, lc[4] = ln_fwd(c_new, lnp[0][4], lnp[1][4])
+    o = _sig(po); tc = np.tanh(oc)
+    return c_new, o * tc, (i, f, gc, o, tc, c_new, lc)
+
+
+def _scal_cell_bwd(dh, dc_in, c_prev, peep, lnp, cache, U, use_ln, clipv):
+    """-> dg (B,4U) wrt the gate pre-activations, dc_prev, dpeep (B,4U) wrt the peephole factors (per sample),
+    dln = (dalpha (5,B,U), dbeta (5,B,U)) per sample (zeros without layer norm)."""
+    i, f, gc, o, tc, c_new, lc = cache
+    sl = lambda v, n: v[:, n * U:(n + 1) * U]
+    B = dh.shape[0]
+    dal = np.zeros((5, B, U), dh.dtype); dbe = np.zeros((5, B, U), dh.dtype)
+
+    def back_ln(d, k):                                     # d: gradient at the (clipped) LN output
+        d = _clip(d, clipv)
+        if not use_ln:
+            return d
+        dx, da, db = ln_bwd(d, lnp[0][k], lc[k])
+        dal[k] = da; dbe[k] = db
+        return dx
+    dpo = back_ln(dh * tc * o * (1 - o), 3)
+    dc = dc_in + back_ln(dh * o * (1 - tc * tc), 4) + dpo * sl(peep, 3)
+    dpi = back_ln(dc * gc * i * (1 - i), 0)
+    dpf = back_ln(dc * c_prev * f * (1 - f), 1)
+    dpc = back_ln(dc * i * (1 - gc * gc), 2)
+    dc_prev = dc * f + dpi * sl(peep, 0) + dpf * sl(peep, 1) + dpc * sl(peep, 2)
+    dg = np.concatenate([dpi, dpf, dpc, dpo], axis=1)
+    dpeep = np.concatenate([dpi * c_prev, dpf * c_prev, dpc * c_prev, dpo * c_new], axis=1)
+    return dg, dc_prev, dpeep, (dal, dbe)
+
+
 def scaling_scan_fwd(x, mask, p, spec):
     T, B, D = x.shape
     N, H = spec['N'], spec['H']
+    use_ln, peep = spec.get('ln', False), spec.get('peep', False)
     dt = x.dtype
     inner_in = x @ p['Wi_x'] + p['bi']                    # :951
     outer_in = x @ p['Wo_x']                              # :952
-    ic = np.zeros((B, H), dt); ih = np.zeros((B, H), dt)
-    oc = np.zeros((B, N), dt); oh = np.zeros((B, N), dt)
+    one = np.ones((B, 1), dt)
+    ic = one @ p['ic0']; ih = one @ p['ih0']; oc = one @ p['oc0']; oh = one @ p['oh0']   # :1127-1131
     order = range(T - 1, -1, -1) if spec.get('backwards') else range(T)
     hid_i = np.zeros((T, B, H), dt); hid_o = np.zeros((T, B, N), dt)
     cache = [None] * T
+    zeroN = np.zeros((B, 4 * N), dt)
     for t in order:
         m = mask[t][:, None] != 0
         ig = inner_in[t] + ih @ p['Wi_h'] + oh @ p['Wi_o']            # :973-975
-        ii = _sig(ig[:, 0:H]); if_ = _sig(ig[:, H:2 * H]); igc = np.tanh(ig[:, 2 * H:3 * H])
-        ic_new = if_ * ic + ii * igc                                  # :1005
-        io = _sig(ig[:, 3 * H:4 * H])
-        itc = np.tanh(ic_new)
-        ih_new = io * itc                                             # :1025
+        ic_new, ih_new, cin = _scal_cell_fwd(ig, ic, p['wpeep'][None, :], (p['ln_ia'], p['ln_ib']), H, use_ln)
         s_in = ih_new @ p['S_in'] + p['s_in']                         # :1030
         s_hid = ih_new @ p['S_hid'] + p['s_hid']                      # :1031
+        s_cl = ih_new @ p['S_cell'] + p['s_cell'] if peep else zeroN  # :1032
         s_b = ih_new @ p['S_bias'] + p['s_bias']                      # :1033
         a = oh @ p['Wo_h']
         og = s_in * outer_in[t] + s_hid * a + s_b                     # :1038-1040
-        oi = _sig(og[:, 0:N]); of = _sig(og[:, N:2 * N]); ogc = np.tanh(og[:, 2 * N:3 * N])
-        oc_new = of * oc + oi * ogc                                   # :1071
-        oo = _sig(og[:, 3 * N:4 * N])
-        otc = np.tanh(oc_new)
-        oh_new = oo * otc                                             # :1091
-        cache[t] = (m, ic, ih, oc, oh, ii, if_, igc, io, itc, ih_new, s_in, s_hid, a, oi, of, ogc, oo, otc)
+        oc_new, oh_new, cout = _scal_cell_fwd(og, oc, s_cl, (p['ln_oa'], p['ln_ob']), N, use_ln)
+        cache[t] = (m, ic, ih, oc, oh, ih_new, s_in, s_hid, s_cl, a, cin, cout)
         ic = np.where(m, ic_new, ic); ih = np.where(m, ih_new, ih)    # step_masked :1097-1118
         oc = np.where(m, oc_new, oc); oh = np.where(m, oh_new, oh)
         hid_i[t] = ih; hid_o[t] = oh
@@ -471,6 +514,7 @@ def scaling_scan_bwd(dhid_i, dhid_o, x, fwd_cache, p, spec):
     cache, inner_in, outer_in = fwd_cache
     T, B, D = x.shape
     N, H = spec['N'], spec['H']
+    use_ln, peep = spec.get('ln', False), spec.get('peep', False)
     clipv = spec.get('grad_clip', 0)
     dt = dhid_o.dtype
     order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
@@ -479,43 +523,42 @@ def scaling_scan_bwd(dhid_i, dhid_o, x, fwd_cache, p, spec):
     dih = np.zeros((B, H), dt); dic = np.zeros((B, H), dt)
     d_inner_in = np.zeros((T, B, 4 * H), dt); d_outer_in = np.zeros((T, B, 4 * N), dt)
     for t in reversed(order):
-        (m, ic_prev, ih_prev, oc_prev, oh_prev, ii, if_, igc, io, itc, ih_new, s_in, s_hid, a,
-         oi, of, ogc, oo, otc) = cache[t]
+        (m, ic_prev, ih_prev, oc_prev, oh_prev, ih_new, s_in, s_hid, s_cl, a, cin, cout) = cache[t]
         doh_t = dhid_o[t] + doh
         dih_t = dhid_i[t] + dih
         doh_new = np.where(m, doh_t, 0); doh_prev = np.where(m, 0, doh_t)
         doc_new = np.where(m, doc, 0); doc_prev = np.where(m, 0, doc)
         dih_new = np.where(m, dih_t, 0); dih_prev = np.where(m, 0, dih_t)
         dic_new = np.where(m, dic, 0); dic_prev = np.where(m, 0, dic)
-        # outer cell
-        doo = doh_new * otc
-        doc_new = doc_new + _clip(doh_new * oo * (1 - otc * otc), clipv)      # clip on outer_outcell
-        dog = np.concatenate([doc_new * ogc * oi * (1 - oi), doc_new * oc_prev * of * (1 - of),
-                              doc_new * oi * (1 - ogc * ogc), doo * oo * (1 - oo)], axis=1)
-        dog = _clip(dog, clipv)
-        doc_prev = doc_prev + doc_new * of
+        # outer cell (:1042-1091)
+        dog, dcp, ds_cl, (dal, dbe) = _scal_cell_bwd(doh_new, doc_new, oc_prev, s_cl, (p['ln_oa'], p['ln_ob']), cout, N,
+                                                     use_ln, clipv)
+        doc_prev = doc_prev + dcp
+        g_['ln_oa'] += dal.sum(1); g_['ln_ob'] += dbe.sum(1)
         ds_in = dog * outer_in[t]; d_outer_in[t] = dog * s_in
         ds_hid = dog * a; da = dog * s_hid
         ds_b = dog
         g_['Wo_h'] += oh_prev.T @ da
         doh_prev = doh_prev + da @ p['Wo_h'].T
-        for nm, dsv in (('in', ds_in), ('hid', ds_hid), ('bias', ds_b)):
+        maps = [('in', ds_in), ('hid', ds_hid), ('bias', ds_b)] + ([('cell', ds_cl)] if peep else [])
+        for nm, dsv in maps:
             g_['S_' + nm] += ih_new.T @ dsv
             g_['s_' + nm] += dsv.sum(0)
             dih_new = dih_new + dsv @ p['S_' + nm].T
-        # inner cell
-        dio = dih_new * itc
-        dic_new = dic_new + _clip(dih_new * io * (1 - itc * itc), clipv)      # clip on inner_outcell
-        dig = np.concatenate([dic_new * igc * ii * (1 - ii), dic_new * ic_prev * if_ * (1 - if_),
-                              dic_new * ii * (1 - igc * igc), dio * io * (1 - io)], axis=1)
-        dig = _clip(dig, clipv)
-        dic_prev = dic_prev + dic_new * if_
+        # inner cell (:977-1025)
+        dig, dcp, dwp, (dal, dbe) = _scal_cell_bwd(dih_new, dic_new, ic_prev, p['wpeep'][None, :], (p['ln_ia'], p['ln_ib']),
+                                                   cin, H, use_ln, clipv)
+        dic_prev = dic_prev + dcp
+        g_['wpeep'] += dwp.sum(0)
+        g_['ln_ia'] += dal.sum(1); g_['ln_ib'] += dbe.sum(1)
         d_inner_in[t] = dig
         g_['Wi_h'] += ih_prev.T @ dig
         g_['Wi_o'] += oh_prev.T @ dig
         dih_prev = dih_prev + dig @ p['Wi_h'].T
         doh_prev = doh_prev + dig @ p['Wi_o'].T
         doh, doc, dih, dic = doh_prev, doc_prev, dih_prev, dic_prev
+    g_['ic0'] += dic.sum(0, keepdims=True); g_['ih0'] += dih.sum(0, keepdims=True)
+    g_['oc0'] += doc.sum(0, keepdims=True); g_['oh0'] += doh.sum(0, keepdims=True)
     xf = x.reshape(T * B, D)
     g_['Wi_x'] += xf.T @ d_inner_in.reshape(T * B, -1)
     g_['bi'] += d_inner_in.sum((0, 1))
@@ -1081,24 +1124,38 @@ class ProjectionHyperLSTMLayerO(OracleLayer):
 
 
 class ScalingHyperLSTMLayerO(OracleLayer):
-    """libs/lasagne_libs/hyper_layers.py:525-1205 (use_peepholes=False, use_layer_norm=False).  forward
-    returns the OUTER hidden sequence (what models/gating_hyper_nets.py:66-98 feeds upward); the inner
-    hidden sequence is kept in self.inner_hid."""
+    """libs/lasagne_libs/hyper_layers.py:525-1205 with its options use_peepholes, use_layer_norm, learn_init.  forward
+    returns the OUTER hidden sequence (what models/gating_hyper_nets.py:66-98 feeds upward); the inner hidden
+    sequence is kept in self.inner_hid."""
     GI = ('W_inner_in_to_inner_{}', 'W_inner_hid_to_inner_{}', 'W_outer_hid_to_inner_{}', 'b_inner_{}')
+    LN5 = GATES_REC + ('outcell',)
 
-    def __init__(self, P, num_inner_units, num_outer_units, grad_clipping=0, backwards=False):
+    def __init__(self, P, num_inner_units, num_outer_units, grad_clipping=0, backwards=False, use_peepholes=False,
+                 use_layer_norm=False, learn_init=False):
         self.P = P
-        self.spec = dict(N=num_outer_units, H=num_inner_units, grad_clip=grad_clipping, backwards=backwards)
+        self.spec = dict(N=num_outer_units, H=num_inner_units, grad_clip=grad_clipping, backwards=backwards,
+                         peep=use_peepholes, ln=use_layer_norm, learn_init=learn_init)
 
     def forward(self, x, mask, cond=None):
-        P = self.P; G = GATES_REC
+        P = self.P; G = GATES_REC; sp = self.spec
+        N, H = sp['N'], sp['H']
+        dt = np.asarray(x).dtype
+        zH = np.zeros(H, dt); zHN = np.zeros((H, N), dt); zN = np.zeros(N, dt)
+        pk = lambda fmt, z: np.concatenate([P[fmt.format(g)] if (sp['peep'] and g != 'cell') else z for g in G], axis=-1)
+        lnv = lambda pre, wb, U: np.stack([P['%s_%s_ln_%s' % (wb, pre, g)] if sp['ln'] else np.zeros(U, dt) for g in self.LN5])
+        ini = lambda nm, U: P[nm] if sp['learn_init'] else np.zeros((1, U), dt)
         self.p = dict(Wi_x=_stack(P, 'W_inner_in_to_inner_{}', G), Wi_h=_stack(P, 'W_inner_hid_to_inner_{}', G),
                       Wi_o=_stack(P, 'W_outer_hid_to_inner_{}', G), bi=_stack(P, 'b_inner_{}', G, 0),
                       Wo_x=_stack(P, 'W_outer_in_to_outer_{}', G), Wo_h=_stack(P, 'W_outer_hid_to_outer_{}', G),
                       S_in=_stack(P, 'W_inner_hid_to_outer_in_{}', G), s_in=_stack(P, 'b_inner_hid_to_outer_in_{}', G, 0),
                       S_hid=_stack(P, 'W_inner_hid_to_outer_hid_{}', G), s_hid=_stack(P, 'b_inner_hid_to_outer_hid_{}', G, 0),
                       S_bias=_stack(P, 'W_inner_hid_to_outer_bias_{}', G),
-                      s_bias=_stack(P, 'b_inner_hid_to_outer_bias_{}', G, 0))
+                      s_bias=_stack(P, 'b_inner_hid_to_outer_bias_{}', G, 0),
+                      wpeep=pk('W_inner_cell_to_inner_{}', zH), S_cell=pk('W_inner_hid_to_outer_cell_{}', zHN),
+                      s_cell=pk('b_inner_hid_to_outer_cell_{}', zN),
+                      ln_ia=lnv('inner', 'W', H), ln_ib=lnv('inner', 'b', H), ln_oa=lnv('outer', 'W', N), ln_ob=lnv('outer', 'b', N),
+                      ic0=ini('inner_cell_init', H), ih0=ini('inner_hid_init', H), oc0=ini('outer_cell_init', N),
+                      oh0=ini('outer_hid_init', N))
         self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
         hid_i, hid_o, self.cache = scaling_scan_fwd(self.x, m, self.p, self.spec)
         self.inner_hid = _tm(hid_i)
@@ -1108,7 +1165,7 @@ class ScalingHyperLSTMLayerO(OracleLayer):
         dyo = _tm(dy)
         dyi = np.zeros(dyo.shape[:2] + (self.spec['H'],), dyo.dtype) if d_inner is None else _tm(d_inner)
         dx, g = scaling_scan_bwd(dyi, dyo, self.x, self.cache, self.p, self.spec)
-        G = {}; G4 = GATES_REC
+        G = {}; G4 = GATES_REC; sp = self.spec
         for key, fmt in (('Wi_x', 'W_inner_in_to_inner_{}'), ('Wi_h', 'W_inner_hid_to_inner_{}'),
                          ('Wi_o', 'W_outer_hid_to_inner_{}'), ('Wo_x', 'W_outer_in_to_outer_{}'),
                          ('Wo_h', 'W_outer_hid_to_outer_{}'), ('S_in', 'W_inner_hid_to_outer_in_{}'),
@@ -1117,6 +1174,18 @@ class ScalingHyperLSTMLayerO(OracleLayer):
         for key, fmt in (('bi', 'b_inner_{}'), ('s_in', 'b_inner_hid_to_outer_in_{}'),
                          ('s_hid', 'b_inner_hid_to_outer_hid_{}'), ('s_bias', 'b_inner_hid_to_outer_bias_{}')):
             _unstack_into(G, fmt, G4, g[key], axis=0)
+        if sp['peep']:
+            tmp = {}
+            _unstack_into(tmp, 'W_inner_cell_to_inner_{}', G4, g['wpeep'], axis=0)
+            _unstack_into(tmp, 'W_inner_hid_to_outer_cell_{}', G4, g['S_cell'])
+            _unstack_into(tmp, 'b_inner_hid_to_outer_cell_{}', G4, g['s_cell'], axis=0)
+            G.update({k: v for k, v in tmp.items() if not k.endswith('_cell')})        # the cell gate has no peephole
+        if sp['ln']:
+            for pre, ka, kb in (('inner', 'ln_ia', 'ln_ib'), ('outer', 'ln_oa', 'ln_ob')):
+                for k, gname in enumerate(self.LN5):
+                    G['W_%s_ln_%s' % (pre, gname)] = g[ka][k]; G['b_%s_ln_%s' % (pre, gname)] = g[kb][k]
+        if sp['learn_init']:
+            G.update(inner_cell_init=g['ic0'], inner_hid_init=g['ih0'], outer_cell_init=g['oc0'], outer_hid_init=g['oh0'])
         self.grads = G
         return _tm(dx)
 

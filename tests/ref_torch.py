@@ -321,9 +321,11 @@ def seqsum_lhuc_net(ss, layers, x, mask, N, npl, clip=0):
     return out
 
 
-def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False):
-    """libs/lasagne_libs/hyper_layers.py:850-1205 with use_peepholes=False, use_layer_norm=False
-    (peephole vectors and scale_outer_cell are zero constants and are left out).  Returns outer hid."""
+def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False, use_peepholes=False, use_layer_norm=False,
+                        learn_init=False, return_inner=False):
+    """libs/lasagne_libs/hyper_layers.py:850-1205, line by line.  Without use_peepholes the peephole vectors and the
+    scale_outer_cell map are zero constants (:585,:716-723); the cell gate's peephole is a zero constant always
+    (cell_trainable=False, :642-644,:791-793).  Returns outer hid (or [inner hid, outer hid])."""
     c = lambda fmt, dim=1: _cat(P, fmt, G_R, dim)
     W_ii = c('W_inner_in_to_inner_{}'); W_hi = c('W_inner_hid_to_inner_{}'); W_oi = c('W_outer_hid_to_inner_{}')
     b_i = c('b_inner_{}', 0)
@@ -331,34 +333,62 @@ def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False):
     W_hd = c('W_inner_hid_to_outer_hid_{}'); b_hd = c('b_inner_hid_to_outer_hid_{}', 0)
     W_bs = c('W_inner_hid_to_outer_bias_{}'); b_bs = c('b_inner_hid_to_outer_bias_{}', 0)
     W_oo_in = c('W_outer_in_to_outer_{}'); W_oo = c('W_outer_hid_to_outer_{}')
+    zH = torch.zeros(H, dtype=x.dtype); zHN = torch.zeros(H, N, dtype=x.dtype); zN = torch.zeros(N, dtype=x.dtype)
+    pk = lambda g: P['W_inner_cell_to_inner_' + g] if (use_peepholes and g != 'cell') else zH
+    W_cl = torch.cat([P['W_inner_hid_to_outer_cell_' + g] if (use_peepholes and g != 'cell') else zHN for g in G_R], 1)
+    b_cl = torch.cat([P['b_inner_hid_to_outer_cell_' + g] if (use_peepholes and g != 'cell') else zN for g in G_R], 0)
+
+    def lnorm(v, pre, g):
+        if not use_layer_norm:
+            return v
+        out = (v - v.mean(1, keepdim=True)) / torch.sqrt(v.var(1, unbiased=False, keepdim=True) + EPS)
+        return P['W_%s_ln_%s' % (pre, g)][None, :] * out + P['b_%s_ln_%s' % (pre, g)][None, :]
+
     inp = x.transpose(0, 1)
     m = mask.transpose(0, 1).unsqueeze(-1)
     B = inp.shape[1]
     inner_input = inp @ W_ii + b_i
     outer_input = inp @ W_oo_in
+    sl = lambda v, n, U: v[:, n * U:(n + 1) * U]
 
     def step(inner_input_n, outer_input_n, mask_n, ic_prev, ih_prev, oc_prev, oh_prev):
-        ig = inner_input_n + ih_prev @ W_hi + oh_prev @ W_oi
-        i_in = grad_clip(ig[:, 0:H], clip); i_f = grad_clip(ig[:, H:2 * H], clip); i_c = grad_clip(ig[:, 2 * H:3 * H], clip)
-        inner_cell = torch.sigmoid(i_f) * ic_prev + torch.sigmoid(i_in) * torch.tanh(i_c)
-        i_o = grad_clip(ig[:, 3 * H:4 * H], clip)
-        inner_outcell = grad_clip(inner_cell, clip)
-        inner_hid = torch.sigmoid(i_o) * torch.tanh(inner_outcell)
-        s_in = inner_hid @ W_in + b_in; s_hid = inner_hid @ W_hd + b_hd; s_b = inner_hid @ W_bs + b_bs
-        og = s_in * outer_input_n + s_hid * (oh_prev @ W_oo) + s_b
-        o_in = grad_clip(og[:, 0:N], clip); o_f = grad_clip(og[:, N:2 * N], clip); o_c = grad_clip(og[:, 2 * N:3 * N], clip)
-        outer_cell = torch.sigmoid(o_f) * oc_prev + torch.sigmoid(o_in) * torch.tanh(o_c)
-        o_o = grad_clip(og[:, 3 * N:4 * N], clip)
-        outer_outcell = grad_clip(outer_cell, clip)
-        outer_hid = torch.sigmoid(o_o) * torch.tanh(outer_outcell)
+        ig = inner_input_n + ih_prev @ W_hi + oh_prev @ W_oi                                   # :973-975
+        i_in = sl(ig, 0, H) + ic_prev * pk('ingate'); i_f = sl(ig, 1, H) + ic_prev * pk('forgetgate')
+        i_c = sl(ig, 2, H) + ic_prev * pk('cell')                                              # :977-979
+        i_in = grad_clip(lnorm(i_in, 'inner', 'ingate'), clip); i_f = grad_clip(lnorm(i_f, 'inner', 'forgetgate'), clip)
+        i_c = grad_clip(lnorm(i_c, 'inner', 'cell'), clip)                                     # :981-1001
+        inner_cell = torch.sigmoid(i_f) * ic_prev + torch.sigmoid(i_in) * torch.tanh(i_c)      # :1003-1005
+        i_o = sl(ig, 3, H) + inner_cell * pk('outgate')                                        # :1006
+        i_o = grad_clip(lnorm(i_o, 'inner', 'outgate'), clip)
+        inner_outcell = grad_clip(lnorm(inner_cell, 'inner', 'outcell'), clip)                 # :1007-1022
+        inner_hid = torch.sigmoid(i_o) * torch.tanh(inner_outcell)                             # :1025
+        s_in = inner_hid @ W_in + b_in; s_hid = inner_hid @ W_hd + b_hd                        # :1030-1033
+        s_cl = inner_hid @ W_cl + b_cl; s_b = inner_hid @ W_bs + b_bs
+        og = s_in * outer_input_n + s_hid * (oh_prev @ W_oo) + s_b                             # :1038-1040
+        o_in = sl(og, 0, N) + oc_prev * sl(s_cl, 0, N); o_f = sl(og, 1, N) + oc_prev * sl(s_cl, 1, N)
+        o_c = sl(og, 2, N) + oc_prev * sl(s_cl, 2, N)                                          # :1042-1044
+        o_in = grad_clip(lnorm(o_in, 'outer', 'ingate'), clip); o_f = grad_clip(lnorm(o_f, 'outer', 'forgetgate'), clip)
+        o_c = grad_clip(lnorm(o_c, 'outer', 'cell'), clip)
+        outer_cell = torch.sigmoid(o_f) * oc_prev + torch.sigmoid(o_in) * torch.tanh(o_c)      # :1069-1071
+        o_o = sl(og, 3, N) + outer_cell * sl(s_cl, 3, N)                                       # :1072
+        o_o = grad_clip(lnorm(o_o, 'outer', 'outgate'), clip)
+        outer_outcell = grad_clip(lnorm(outer_cell, 'outer', 'outcell'), clip)
+        outer_hid = torch.sigmoid(o_o) * torch.tanh(outer_outcell)                             # :1091
         k = mask_n != 0
         return [torch.where(k, inner_cell, ic_prev), torch.where(k, inner_hid, ih_prev),
                 torch.where(k, outer_cell, oc_prev), torch.where(k, outer_hid, oh_prev)]
 
-    z = lambda n: torch.zeros(B, n, dtype=x.dtype)
-    outs = _scan(step, [inner_input, outer_input, m], [z(H), z(H), z(N), z(N)], backwards)
+    ones = torch.ones(B, 1, dtype=x.dtype)
+    init = lambda nm, n: ones @ P[nm] if learn_init else torch.zeros(B, n, dtype=x.dtype)     # :1127-1131
+    outs = _scan(step, [inner_input, outer_input, m],
+                 [init('inner_cell_init', H), init('inner_hid_init', H), init('outer_cell_init', N), init('outer_hid_init', N)],
+                 backwards)
     hid = outs[3].transpose(0, 1)
-    return hid.flip(1) if backwards else hid
+    hid = hid.flip(1) if backwards else hid
+    if return_inner:
+        ih = outs[1].transpose(0, 1)
+        return [ih.flip(1) if backwards else ih, hid]
+    return hid
 
 
 def hyperlhuc_layer(P, x, mask, N, H, Z, clip=0, backwards=False, reparam='relu'):

@@ -296,6 +296,39 @@ def test_scaling_hyper_reference_widths():
     run_case(net, b, calibrate=True)
 
 
+@pytest.mark.parametrize('peep,ln,li', [(True, False, False), (False, True, False), (False, False, True), (True, True, True)])
+@pytest.mark.parametrize('clip', [0.0, 0.05])
+def test_scaling_hyper_options_small(peep, ln, li, clip):
+    """use_peepholes / use_layer_norm / learn_init of ScalingHyperLSTMLayer (hyper_layers.py:977-1091,:1127-1131) on
+    the step-loop path of step_scaling.hip: two stacked bidirectional layers, ragged lengths, clip biting."""
+    from asr_amd.gating_hyper_nets import deep_scaling_hyper_model
+    net = deep_scaling_hyper_model(None, None, 5, 6, [8, 4], [12, 8], use_peepholes=peep, use_layer_norm=ln,
+                                   learn_init=li, grad_clipping=clip, device=_dev(), seed=51)
+    perturb_params(net, 52, 0.15)
+    b = make_batch(np.random.default_rng(53), 3, 7, 5, 6)
+    run_case(net, b)
+
+
+def test_scaling_hyper_options_timit_script_shape():
+    """The configuration scripts/timit/exp_scalehyper.py runs (:26-41,:331-338): one bidirectional layer, 64 inner /
+    128 outer units, layer norm and learned initial rows, 123 inputs, 63 classes; 18 rows = two batch chunks; the
+    inner hidden sequences of get_inner_hid=True against the oracle's."""
+    from asr_amd.gating_hyper_nets import deep_scaling_hyper_model
+    out = deep_scaling_hyper_model(None, None, 123, 63, [64], [128], use_layer_norm=True, learn_init=True,
+                                   grad_clipping=1.0, get_inner_hid=True, device=_dev(), seed=54)
+    net = out[-1]; inner = out[:-1]
+    perturb_params(net, 55, 0.05)
+    b = make_batch(np.random.default_rng(56), 18, 29, 123, 63)
+    run_case(net, b)
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    onet.posteriors(b['x'], b['mask'], None)
+    x = torch.from_numpy(b['x']).to(net.device); m = torch.from_numpy(b['mask']).to(net.device)
+    net.posteriors(x, m, None)
+    for k, h in enumerate(inner):
+        got = h.get_output().cpu().numpy().reshape(29, 18, -1).transpose(1, 0, 2)
+        assert relerr(got, onet.layers[0][k].inner_hid) < 2e-5, k
+
+
 @pytest.mark.parametrize('is_bidir,clip,reparam', [(True, 0.05, 'relu'), (False, 0.0, 'relu'), (True, 0.0, 'exp'),
                                                     (True, 0.05, '2sigmoid'), (False, 0.0, 'identity')])
 def test_hyperlhuc_small(is_bidir, clip, reparam):

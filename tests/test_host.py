@@ -53,6 +53,8 @@ int main(void) {
          offsetof(asr_hyper_scan_desc, dir), offsetof(asr_hyper_dir, dD));
   printf("%zu %zu %zu %zu\\n", sizeof(asr_prjhyper_dir), sizeof(asr_prjhyper_desc), offsetof(asr_prjhyper_desc, dir),
          offsetof(asr_prjhyper_dir, douto));
+  printf("%zu %zu %zu %zu\\n", sizeof(asr_scaling_dir), sizeof(asr_scaling_desc), offsetof(asr_scaling_desc, dir),
+         offsetof(asr_scaling_dir, dinit));
   return 0;
 }''')
     exe = tmp_path / 'layout'
@@ -64,7 +66,9 @@ int main(void) {
             C.sizeof(_lib.HyperScanDesc), _lib.LstmScanDesc.dir.offset, _lib.LstmDir.dOut.offset,
             _lib.HyperScanDesc.dir.offset, _lib.HyperDir.dD.offset,
             C.sizeof(_lib.PrjHyperDir), C.sizeof(_lib.PrjHyperDesc), _lib.PrjHyperDesc.dir.offset,
-            _lib.PrjHyperDir.douto.offset]
+            _lib.PrjHyperDir.douto.offset,
+            C.sizeof(_lib.ScalingDir), C.sizeof(_lib.ScalingDesc), _lib.ScalingDesc.dir.offset,
+            _lib.ScalingDir.dinit.offset]
     assert got == want
 
 

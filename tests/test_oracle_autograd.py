@@ -119,6 +119,19 @@ def test_scaling_hyper_layer(backwards, clip):
 
 
 @pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('peep,ln,li', [(True, False, False), (False, True, False), (False, False, True), (True, True, True)])
+def test_scaling_hyper_layer_options(backwards, peep, ln, li):
+    """use_peepholes / use_layer_norm / learn_init of ScalingHyperLSTMLayer (hyper_layers.py:977-1091,:1127-1131),
+    with grad_clip biting, against the torch transliteration differentiated by autograd."""
+    rng = np.random.default_rng(29)
+    Hs = 6
+    P = make_params(rng, specs.scaling_hyper_params(D, Hs, N, peep, ln, li), perturb=0.3, scale=1.5)
+    b = make_batch(rng, B, T, D, C)
+    lay = O.ScalingHyperLSTMLayerO(P, Hs, N, 0.3, backwards, peep, ln, li)
+    _check(lay, lambda Pt, x, m, c: R.scaling_hyper_layer(Pt, x, m, N, Hs, 0.3, backwards, peep, ln, li), P, b['x'], b['mask'])
+
+
+@pytest.mark.parametrize('backwards', [False, True])
 @pytest.mark.parametrize('clip,reparam', [(0, 'relu'), (0.3, 'relu'), (0.3, 'exp'), (0, '2sigmoid'), (0, 'identity')])
 def test_hyperlhuc_layer(backwards, clip, reparam):
     rng = np.random.default_rng(23)
