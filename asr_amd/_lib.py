@@ -38,9 +38,9 @@ class HyperDir(C.Structure):
 
 class PrjHyperDir(C.Structure):
     _fields_ = [('reverse', i32)] + [(n, fp) for n in (
-        'inner_in', 'outer_in', 'Wio', 'Wi_p', 'S', 's', 'Wo_o', 'Wo_p', 'ai', 'bi_c', 'ao', 'bo_c', 'hid',
-        'gi', 'go', 'ci', 'co', 'ri', 'ro', 'xhi', 'xho', 'rsi', 'rso', 'sc', 'a',
-        'dhid', 'dii', 'doi', 'dsc', 'da', 'dh', 'douti', 'douto')]
+        'inner_in', 'outer_in', 'Wf', 'W3', 's', 'ai', 'bi_c', 'ao', 'bo_c', 'r',
+        'gi', 'go', 'ci', 'co', 'xhi', 'xho', 'rsi', 'rso', 'sc', 'a',
+        'dr', 'dta', 'doi', 'dsc', 'douti', 'douto')]
 
 
 class PrjHyperDesc(C.Structure):

@@ -4,15 +4,19 @@
 //
 // Why not a mode of the persistent scans: both cells are N units wide with cell layer norm and a
 // projection to F, coupled inside the step through three scale maps (F x 12N); folded weights are
-// ~190 KB per workgroup at N = 512 and the step has 4-6 all-to-all exchanges.  This version keeps the
-// weights in L2 and is launch-bound (~12 launches per step, forward); a persistent kernel is the next
-// step.
+// ~190 KB per workgroup at N = 512 and the step has 4-6 all-to-all exchanges (DESIGN.md 7 prices a persistent kernel).
+//
+// Both projections are folded into their consumers (exact algebra, gradients un-folded by the caller):
+//   [tg | a]_t = [r_i | r_o]_{t-1} . Wf,  Wf (2N,8N) = [[W_ip.W_io[:F], 0], [W_op.W_io[F:], W_op.W_oo]]   (:329-331,:376)
+//   sc_t       = r_i,t . W3 + s,          W3 (N,12N) = W_ip.S                                              (:364-370)
+// so the carried state is r = o*tanh(outcell) of both cells ((T,B,2N), masked like the reference's hid: hid_t =
+// r_t . W_prj is linear, so switching r is switching hid, :441-444), hid = R.W_prj is one GEMM after the loop, and a
+// step is 2 skinny products + 2 cell kernels in each direction of time (7 + 7 before the fold: 334 -> see DESIGN.md).
 //
 // Layouts here are the reference's: gate vectors are gate-major [i | f | c | o] blocks of N, sequences
-// time-major (T,B,.).  The recurrent state that is carried is r = o*tanh(outcell) (N wide, masked like
-// the reference's hid): hid_t = r_t . W_prj is linear, so switching r is switching hid (:441-444).
+// time-major (T,B,.).
 #include "scan_common.h"
-
+#include <stdlib.h>
 #include "step_skinny.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -20,28 +24,24 @@ struct PrjDir {                 // mirrored in include/asr_amd.h (asr_prjhyper_d
     int reverse;
     const float* inner_in;      // (T,B,4N) x.W_in_to_inner + b_inner                 (:316)
     const float* outer_in;      // (T,B,4N) x.W_in_to_outer                           (:317)
-    const float* Wio;           // (2F,4N) [W_inner_to_inner ; W_outer_to_inner]
-    const float* Wi_p;          // (N,F)
-    const float* S;             // (F,12N) [to_in | to_outer | to_bias]
+    const float* Wf;            // (2N,8N) folded recurrent matrix (above)
+    const float* W3;            // (N,12N) W_inner_prj . [to_in | to_outer | to_bias]
     const float* s;             // (12N)
-    const float* Wo_o;          // (F,4N)
-    const float* Wo_p;          // (N,F)
     const float *ai, *bi_c, *ao, *bo_c;   // cell layer norm alpha / beta (N)
-    float* hid;                 // (T,B,2F) [inner_hid | outer_hid]
+    float* r;                   // (T,B,2N) [r_inner | r_outer] state (masked)
     // saved for BPTT
     float *gi, *go;             // (T,B,4N) post-activation gates
     float *ci, *co;             // (T,B,N)  cell state (masked)
-    float *ri, *ro;             // (T,B,N)  r state (masked)
     float *xhi, *xho;           // (T,B,N)  normalised cell
     float *rsi, *rso;           // (T,B)    rstd
     float* sc;                  // (T,B,12N) scale_outer
-    float* a;                   // (T,B,4N)  outer_hid_prev . W_outer_to_outer
+    float* a;                   // (T,B,4N) outer_hid_prev . W_outer_to_outer
     // backward
-    const float* dhid;          // (T,B,2F) dLoss/d hid
-    float *dii, *doi;           // (T,B,4N) d inner gates ; d outer_input
+    float* dr;                  // (T,B,2N) d r_t from outside the loop (dhid . W_prj^T) on entry; rows that are switched
+                                // off add what they pass on to the row of the step before (work)
+    float* dta;                 // (T,B,8N) [d inner gate pre-activations | d a]
+    float* doi;                 // (T,B,4N) d outer_input
     float* dsc;                 // (T,B,12N)
-    float* da;                  // (T,B,4N)
-    float* dh;                  // (T,B,2F) total d hid_t = [d inner_hid | d outer_hid]
     float *douti, *douto;       // (T,B,N) clipped d outcell
 };
 
@@ -52,12 +52,24 @@ struct PrjArgs {
     const float* mask; int msb, mst;
     PrjDir d[2];
     int t[2], tp[2];            // time index of this step / of the previous forward step (-1: none)
-    float* tg;                  // (ndir,B,4N) recurrent part of the inner gates
-    float *g_c[2], *g_r[2];     // (ndir,B,N) carried d cell / d r state: [0] inner, [1] outer
+    float* g_c[2];              // (ndir,B,N) carried d cell: [0] inner, [1] outer
+    // partial blocks of the skinny products ([split][16 rows][columns], step_skinny.h raw mode), summed by the cell
+    // kernel that consumes them: forward pf = r_{t-1}.Wf (8N columns), p3 = r_inner,t.W3 (12N); backward
+    // pbf = dta_{t+1}.Wf^T (2N: what step t+1 hands to d r_t), pb3 = dsc_t.W3^T (N)
+    float *pf[2], *p3[2], *pbf[2], *pb3[2];
+    int ns_f, ns_3, ns_bf, ns_b3;
+    int first;                  // backward: the first step processed (nothing handed over from a later step)
 };
 
-// one workgroup per (batch row, direction)
-template <int OUTER>
+// Sums of partial blocks: four blocks' loads are in flight together, every load unconditional (a slot past the last
+// split re-reads the last one with weight 0: hipcc waits for a load at the first control-flow join behind it).
+#define PART_SUM_BEGIN(ns) for (int sp0 = 0; sp0 < (ns); sp0 += 4) { _Pragma("unroll") for (int i4 = 0; i4 < 4; ++i4) { \
+    const int sp = min(sp0 + i4, (ns) - 1); const float pw = sp0 + i4 < (ns) ? 1.f : 0.f;
+#define PART_SUM_END } }
+
+// one workgroup per (batch row, direction); NU = units per thread (N <= 256 NU); loads are unconditional
+// (out-of-range units read unit N-1), stores guarded
+template <int OUTER, int NU>
 __global__ __launch_bounds__(256) void prj_cell_fwd_kernel(PrjArgs A) {
     __shared__ float sm[4];
     const int b = blockIdx.x, dir = blockIdx.y;
@@ -69,54 +81,103 @@ __global__ __launch_bounds__(256) void prj_cell_fwd_kernel(PrjArgs A) {
     const float* beta = OUTER ? D.bo_c : D.bi_c;
     float* gsv = (OUTER ? D.go : D.gi) + row * 4 * N;
     float* cst = OUTER ? D.co : D.ci;
-    float* rst = OUTER ? D.ro : D.ri;
-    float cn[PRJ_MAXU], og[PRJ_MAXU], cp[PRJ_MAXU];
+    float* rst = D.r + (OUTER ? N : 0);              // row stride 2N
+    int nn[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) nn[u] = min((int)threadIdx.x + u * 256, N - 1);
+    // recurrent products of the step: sums of the partial blocks
+    float rec[NU][4];                                // inner: recurrent part of the gates (:329-331); outer: a (:376)
+    float scv[NU][12];                               // outer: scale_outer (:364-370)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rec[u][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) scv[u][k] = OUTER ? D.s[k * N + nn[u]] : 0.f;
+    }
+    if (tp >= 0) {
+        const float* pf = A.pf[dir] + (size_t)b * 8 * N + (OUTER ? 4 * N : 0);
+        PART_SUM_BEGIN(A.ns_f)
+            const float* pp = pf + (size_t)sp * 16 * 8 * N;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rec[u][k] += pw * pp[k * N + nn[u]];
+            }
+        PART_SUM_END
+    }
+    if (OUTER) {
+        const float* p3 = A.p3[dir] + (size_t)b * 12 * N;
+        PART_SUM_BEGIN(A.ns_3)
+            const float* pp = p3 + (size_t)sp * 16 * 12 * N;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) scv[u][k] += pw * pp[k * N + nn[u]];
+            }
+        PART_SUM_END
+    }
+    float cn[NU], og[NU], cp[NU], xin[NU][4];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        cp[u] = cst[rowp * N + nn[u]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xin[u][k] = (OUTER ? D.outer_in : D.inner_in)[row * 4 * N + k * N + nn[u]];
+    }
     float s1 = 0.f;
 #pragma unroll
-    for (int u = 0; u < PRJ_MAXU; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int n = threadIdx.x + u * 256;
-        cn[u] = 0.f; og[u] = 0.f; cp[u] = 0.f;
-        if (n < N) {
-            float g[4];
+        float g[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (OUTER) {
-                    const float* sc = D.sc + row * 12 * N;
-                    g[k] = D.outer_in[row * 4 * N + k * N + n] * sc[k * N + n] +
-                           D.a[row * 4 * N + k * N + n] * sc[4 * N + k * N + n] + sc[8 * N + k * N + n];   // :375-377
-                } else {
-                    g[k] = D.inner_in[row * 4 * N + k * N + n] + A.tg[((size_t)dir * A.B + b) * 4 * N + k * N + n];   // :329-331
-                }
-            }
-            const float ig = sigmoidf_(g[0]), fg = sigmoidf_(g[1]), gc = tanhf_(g[2]), o = sigmoidf_(g[3]);
-            cp[u] = tp < 0 ? 0.f : cst[rowp * N + n];
-            cn[u] = fg * cp[u] + ig * gc;                                  // :355 | :401
-            og[u] = o;
+        for (int k = 0; k < 4; ++k)
+            g[k] = OUTER ? xin[u][k] * scv[u][k] + rec[u][k] * scv[u][4 + k] + scv[u][8 + k]      // :375-377
+                         : xin[u][k] + rec[u][k];                                                   // :329-331
+        const float ig = sigmoidf_(g[0]), fg = sigmoidf_(g[1]), gc = tanhf_(g[2]), o = sigmoidf_(g[3]);
+        if (tp < 0) cp[u] = 0.f;
+        cn[u] = fg * cp[u] + ig * gc;                                  // :355 | :401
+        og[u] = o;
+        if (n < N) {
             gsv[n] = ig; gsv[N + n] = fg; gsv[2 * N + n] = gc; gsv[3 * N + n] = o;
+            if (OUTER) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) D.a[row * 4 * N + k * N + n] = rec[u][k];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) D.sc[row * 12 * N + k * N + n] = scv[u][k];
+            }
             s1 += cn[u];
         }
     }
     const float mean = block_sum(s1, sm) / N;
     float s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < PRJ_MAXU; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int n = threadIdx.x + u * 256;
         if (n < N) { const float dlt = cn[u] - mean; s2 += dlt * dlt; }
     }
     const float rstd = 1.0f / sqrtf(block_sum(s2, sm) / N + ASR_EPS);   // ln :9-12
     if (threadIdx.x == 0) (OUTER ? D.rso : D.rsi)[row] = rstd;
 #pragma unroll
-    for (int u = 0; u < PRJ_MAXU; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int n = threadIdx.x + u * 256;
         if (n < N) {
             const float xh = (cn[u] - mean) * rstd;
             (OUTER ? D.xho : D.xhi)[row * N + n] = xh;
             const float r = og[u] * tanhf_(alpha[n] * xh + beta[n]);     // :357-363 | :403-409
-            const float rp = tp < 0 ? 0.f : rst[rowp * N + n];
+            const float rp = tp < 0 ? 0.f : rst[rowp * 2 * N + n];
             cst[row * N + n] = m != 0.f ? cn[u] : cp[u];                   // :441-444
-            rst[row * N + n] = m != 0.f ? r : rp;
+            rst[row * 2 * N + n] = m != 0.f ? r : rp;
         }
     }
+}
+
+template <int OUTER>
+static void prj_cell_fwd_launch(const PrjArgs& A, int ndir, hipStream_t st) {
+    const dim3 grid(A.B, ndir), block(256);
+    if (A.N <= 256) hipLaunchKernelGGL((prj_cell_fwd_kernel<OUTER, 1>), grid, block, 0, st, A);
+    else if (A.N <= 512) hipLaunchKernelGGL((prj_cell_fwd_kernel<OUTER, 2>), grid, block, 0, st, A);
+    else if (A.N <= 1024) hipLaunchKernelGGL((prj_cell_fwd_kernel<OUTER, 4>), grid, block, 0, st, A);
+    else hipLaunchKernelGGL((prj_cell_fwd_kernel<OUTER, PRJ_MAXU>), grid, block, 0, st, A);
 }
 
 // NU = units per thread (N <= 256 NU).  Every load is unconditional (out-of-range units read unit N-1, rows
@@ -137,17 +198,19 @@ __global__ __launch_bounds__(256) void prj_cell_bwd_kernel(PrjArgs A) {
     const float* xhat = (OUTER ? D.xho : D.xhi) + row * N;
     const float rstd = (OUTER ? D.rso : D.rsi)[row];
     float* g_c = A.g_c[OUTER] + ((size_t)dir * A.B + b) * N;
-    float* g_r = A.g_r[OUTER] + ((size_t)dir * A.B + b) * N;
+    const float* dr_t = D.dr + row * 2 * N + (OUTER ? N : 0);
+    float* dr_p = D.dr + rowp * 2 * N + (OUTER ? N : 0);
     float* dout_sv = (OUTER ? D.douto : D.douti) + row * N;
     const float* sc = D.sc + row * 12 * N;
     const float* oin = D.outer_in + row * 4 * N;
     const float* av = D.a + row * 4 * N;
     float gr[NU], gcar[NU], xh[NU], al[NU], be[NU], g4[NU][4], cpr[NU];
     float s_in[NU][4], s_ou[NU][4], x_in[NU][4], x_a[NU][4];
+    int nn[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int n = min((int)threadIdx.x + u * 256, N - 1);
-        gr[u] = g_r[n]; gcar[u] = g_c[n]; xh[u] = xhat[n]; al[u] = alpha[n]; be[u] = beta[n];
+        const int n = nn[u] = min((int)threadIdx.x + u * 256, N - 1);
+        gr[u] = dr_t[n]; gcar[u] = g_c[n]; xh[u] = xhat[n]; al[u] = alpha[n]; be[u] = beta[n];
         cpr[u] = cpv[n];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -157,6 +220,21 @@ __global__ __launch_bounds__(256) void prj_cell_bwd_kernel(PrjArgs A) {
                 x_in[u][k] = oin[k * N + n]; x_a[u][k] = av[k * N + n];
             }
         }
+    }
+    // total d r_t of this cell: + what the recurrent products hand over (their partial blocks)
+    if (!A.first) {
+        const float* pb = A.pbf[dir] + (size_t)b * 2 * N + (OUTER ? N : 0);
+        PART_SUM_BEGIN(A.ns_bf)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) gr[u] += pw * pb[(size_t)sp * 16 * 2 * N + nn[u]];
+        PART_SUM_END
+    }
+    if (!OUTER) {
+        const float* pb = A.pb3[dir] + (size_t)b * N;
+        PART_SUM_BEGIN(A.ns_b3)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) gr[u] += pw * pb[(size_t)sp * 16 * N + nn[u]];
+        PART_SUM_END
     }
     float dxh[NU], do_[NU];
     float s1 = 0.f, s2 = 0.f;
@@ -187,20 +265,21 @@ __global__ __launch_bounds__(256) void prj_cell_bwd_kernel(PrjArgs A) {
             dg[2] = clipf_(dct * ig * (1.f - gc * gc), A.clip);
             dg[3] = clipf_(do_[u] * o * (1.f - o), A.clip);
             g_c[n] = dct * fg;
-            g_r[n] = 0.f;            // a switched-on row passes nothing straight through to t-1
-        }                            // off: the state was copied, g_c / g_r (total) pass through unchanged
+        } else if (tp >= 0) {
+            dr_p[n] += gr[u];        // off: the state was copied, its gradient passes on (g_c stays as it is)
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const size_t i4 = row * 4 * N + k * N + n;
             if (OUTER) {
                 D.doi[i4] = dg[k] * s_in[u][k];                                 // d outer_input
-                D.da[i4] = dg[k] * s_ou[u][k];                                  // d (outer_hid_prev.W)
+                D.dta[row * 8 * N + 4 * N + k * N + n] = dg[k] * s_ou[u][k];     // d (outer_hid_prev.W)
                 float* ds = D.dsc + row * 12 * N;
                 ds[k * N + n] = dg[k] * x_in[u][k];
                 ds[4 * N + k * N + n] = dg[k] * x_a[u][k];
                 ds[8 * N + k * N + n] = dg[k];
             } else {
-                D.dii[i4] = dg[k];
+                D.dta[row * 8 * N + k * N + n] = dg[k];
             }
         }
     }
@@ -223,9 +302,36 @@ struct asr_prjhyper_desc {      // mirrored in include/asr_amd.h
     PrjDir dir[2];
 };
 
+// splits of the four products (functions of N and ndir only, so the workspace can be sized before the call)
+struct PrjSplits { int f, w3, bf, b3; };
+static int prj_target_wgs() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("ASR_SK_WGS");            // tuning aid; default below
+        v = e ? atoi(e) : 0;
+        if (v < 64 || v > 4096) v = 512;
+    }
+    return v;
+}
+static PrjSplits prj_splits(int N, int ndir) {
+    const int tw = prj_target_wgs();
+    PrjSplits s;
+    s.f = skinny_nsplit(false, N, 8 * N, ndir, tw);       // the shorter of the two reduction ranges (zero block)
+    s.w3 = skinny_nsplit(false, N, 12 * N, ndir, tw);
+    s.bf = skinny_nsplit(true, 4 * N, 2 * N, ndir, tw);
+    s.b3 = skinny_nsplit(true, 12 * N, N, ndir, tw);
+    return s;
+}
+static size_t prj_part_floats(int N, int ndir) {
+    const PrjSplits s = prj_splits(N, ndir);
+    const size_t fw = (size_t)s.f * 16 * 8 * N + (size_t)s.w3 * 16 * 12 * N;
+    const size_t bw = (size_t)s.bf * 16 * 2 * N + (size_t)s.b3 * 16 * N;
+    return (fw > bw ? fw : bw) * ndir;
+}
+
 extern "C" size_t asr_prjhyper_ws_bytes(int B, int N, int F, int ndir) {
-    return ((size_t)ndir * B * (4 * N + 4 * N + 2 * F) + (size_t)B * 2 * F + SK_PART_FLOATS) * sizeof(float) +
-           SK_TICKETS * sizeof(unsigned) + 256;
+    (void)F;
+    return ((size_t)2 * ndir * B * N + prj_part_floats(N, ndir)) * sizeof(float) + 256;
 }
 
 static int prj_check(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes) {
@@ -239,42 +345,50 @@ static int prj_check(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes) {
 
 struct PrjHost {
     PrjArgs A;
-    float* zeros;               // (B,2F) zeros: hid before the first step
-    float* part; unsigned* tickets;
     int nd;
     hipStream_t st;
 };
 
-static int prj_args(const asr_prjhyper_desc* d, void* ws, hipStream_t st, PrjHost& H) {
+static void prj_args(const asr_prjhyper_desc* d, void* ws, hipStream_t st, bool backward, PrjHost& H) {
     PrjArgs& A = H.A;
     A.T = d->T; A.B = d->B; A.N = d->N; A.F = d->F; A.ndir = d->ndir; A.clip = d->grad_clip;
     A.b0 = d->b0; A.Btot = d->Btot;
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
     A.d[0] = d->dir[0]; A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
     float* p = (float*)ws;
-    const size_t bn = (size_t)d->ndir * d->B * d->N;
-    A.tg = p; p += 4 * bn;
-    A.g_c[0] = p; p += bn; A.g_c[1] = p; p += bn; A.g_r[0] = p; p += bn; A.g_r[1] = p; p += bn;
-    p += (size_t)d->ndir * d->B * 2 * d->F;             // (spare)
-    H.zeros = p; p += (size_t)d->B * 2 * d->F;
-    H.part = p; p += SK_PART_FLOATS;
-    H.tickets = (unsigned*)p;
+    const int N = d->N;
+    const size_t bn = (size_t)d->ndir * d->B * N;
+    A.g_c[0] = p; p += bn; A.g_c[1] = p; p += bn;
+    p = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    const PrjSplits s = prj_splits(N, d->ndir);
+    A.ns_f = s.f; A.ns_3 = s.w3; A.ns_bf = s.bf; A.ns_b3 = s.b3; A.first = 0;
+    for (int k = 0; k < 2; ++k) {
+        const int kk = k < d->ndir ? k : 0;
+        if (!backward) {
+            float* q = p + (size_t)kk * ((size_t)s.f * 16 * 8 * N + (size_t)s.w3 * 16 * 12 * N);
+            A.pf[k] = q; A.p3[k] = q + (size_t)s.f * 16 * 8 * N; A.pbf[k] = A.pb3[k] = nullptr;
+        } else {
+            float* q = p + (size_t)kk * ((size_t)s.bf * 16 * 2 * N + (size_t)s.b3 * 16 * N);
+            A.pbf[k] = q; A.pb3[k] = q + (size_t)s.bf * 16 * 2 * N; A.pf[k] = A.p3[k] = nullptr;
+        }
+    }
     H.nd = d->ndir; H.st = st;
-    // the tickets start at zero (every launch leaves them at zero again)
-    if (hipMemsetAsync(H.tickets, 0, SK_TICKETS * sizeof(unsigned), st) != hipSuccess) return ASR_ERR_LAUNCH;
-    return ASR_OK;
 }
 
-// one skinny product per direction, one launch: pointers by direction
+// one skinny product per direction, one launch: pointers by direction; the partial blocks go to Cp (raw mode).
+// zfrom / zk0 / zk1: the zero block of Wf (step_skinny.h), zfrom < 0 for a dense matrix
 static int prj_mm(PrjHost& H, bool nt, const float* const A[2], int lda, const float* const W[2], int ldw,
-                  const float* const bias[2], float* const Cm[2], int ldc, int K, int Nc, int beta) {
+                  float* const Cp[2], int K, int Nc, int ns, int zfrom, int zk0, int zk1) {
     SkinnyArgs S;
     for (int k = 0; k < SK_MAXP; ++k) {
         const int kk = k < H.nd ? k : 0;
-        S.p[k].A = A[kk]; S.p[k].W = W[kk]; S.p[k].bias = bias ? bias[kk] : nullptr; S.p[k].C = Cm[kk];
+        S.p[k].A = A[kk]; S.p[k].W = W[kk]; S.p[k].bias = nullptr; S.p[k].C = Cp[kk];
     }
-    S.lda = lda; S.ldw = ldw; S.ldc = ldc; S.Bm = H.A.B; S.K = K; S.Nc = Nc; S.beta = beta; S.nsplit = 1;
-    S.part = H.part; S.tickets = H.tickets;
+    S.lda = lda; S.ldw = ldw; S.ldc = Nc; S.Bm = H.A.B; S.K = K; S.Nc = Nc; S.beta = 0; S.nsplit = ns;
+    S.raw = 1;
+    if (zfrom < 0) skinny_no_zero_block(S, nt);
+    else { S.zfrom = zfrom; S.zk0 = zk0; S.zk1 = zk1; }
+    S.part = nullptr; S.tickets = nullptr;
     return skinny(nt, S, H.nd, H.st);
 }
 
@@ -293,44 +407,35 @@ extern "C" int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
     if (rc) return rc;
     for (int k = 0; k < d->ndir; ++k) {
         const PrjDir& D = d->dir[k];
-        if (!D.inner_in || !D.outer_in || !D.Wio || !D.Wi_p || !D.S || !D.s || !D.Wo_o || !D.Wo_p || !D.ai || !D.bi_c ||
-            !D.ao || !D.bo_c || !D.hid || !D.gi || !D.go || !D.ci || !D.co || !D.ri || !D.ro || !D.xhi || !D.xho ||
-            !D.rsi || !D.rso || !D.sc || !D.a)
+        if (!D.inner_in || !D.outer_in || !D.Wf || !D.W3 || !D.s || !D.ai || !D.bi_c || !D.ao || !D.bo_c || !D.r || !D.gi ||
+            !D.go || !D.ci || !D.co || !D.xhi || !D.xho || !D.rsi || !D.rso || !D.sc || !D.a)
             return ASR_ERR_ARG;
     }
     if (d->T == 0) return ASR_OK;
     PrjHost H;
-    if ((rc = prj_args(d, ws, st, H))) return rc;
+    prj_args(d, ws, st, false, H);
     PrjArgs& A = H.A;
-    const int T = d->T, B = d->B, N = d->N, F = d->F;
-    if (hipMemsetAsync(H.zeros, 0, (size_t)B * 2 * F * sizeof(float), st) != hipSuccess) return ASR_ERR_LAUNCH;
+    const int T = d->T, N = d->N;
+    const bool zb = (N % 16) == 0;          // Wf's zero block [0,N) x [4N,8N) in whole 64-column blocks
     for (int step = 0; step < T; ++step) {
         prj_times(d, A, step);
-        const float *hprev[2], *ohprev[2], *ri[2], *ro[2], *hrow_c[2];
-        const float *Wio[2], *Wip[2], *Sm[2], *sb[2], *Woo[2], *Wop[2];
-        float *tg[2], *hrow[2], *ohrow[2], *sc[2], *a[2];
+        const float *rprev[2], *rrow[2], *Wf[2], *W3[2];
         for (int k = 0; k < 2; ++k) {
             const int kk = k < d->ndir ? k : 0;
             const PrjDir& D = A.d[kk];
-            const size_t row0 = (size_t)A.t[kk] * d->Btot + d->b0;
-            hprev[k] = A.tp[kk] < 0 ? H.zeros : D.hid + ((size_t)A.tp[kk] * d->Btot + d->b0) * 2 * F;
-            ohprev[k] = hprev[k] + F;
-            hrow[k] = D.hid + row0 * 2 * F; hrow_c[k] = hrow[k]; ohrow[k] = hrow[k] + F;
-            ri[k] = D.ri + row0 * N; ro[k] = D.ro + row0 * N;
-            sc[k] = D.sc + row0 * 12 * N; a[k] = D.a + row0 * 4 * N;
-            tg[k] = A.tg + (size_t)kk * B * 4 * N;
-            Wio[k] = D.Wio; Wip[k] = D.Wi_p; Sm[k] = D.S; sb[k] = D.s; Woo[k] = D.Wo_o; Wop[k] = D.Wo_p;
+            rprev[k] = D.r + ((size_t)(A.tp[kk] < 0 ? 0 : A.tp[kk]) * d->Btot + d->b0) * 2 * N;
+            rrow[k] = D.r + ((size_t)A.t[kk] * d->Btot + d->b0) * 2 * N;
+            Wf[k] = D.Wf; W3[k] = D.W3;
         }
-        // recurrent part of the inner gates                                                      :329-331
-        if ((rc = prj_mm(H, false, hprev, 2 * F, Wio, 4 * N, nullptr, tg, 4 * N, 2 * F, 4 * N, 0))) return rc;
-        hipLaunchKernelGGL(prj_cell_fwd_kernel<0>, dim3(B, d->ndir), dim3(256), 0, st, A);
+        // recurrent part of the inner gates and a, from the previous r of both cells (zero before the first step:
+        // no launch, the cells skip the partial blocks)                                            :329-331,:376
+        if (step > 0 && (rc = prj_mm(H, false, rprev, 2 * N, Wf, 8 * N, A.pf, 2 * N, 8 * N, A.ns_f, zb ? 4 * N : -1, N, 2 * N)))
+            return rc;
+        prj_cell_fwd_launch<0>(A, d->ndir, st);
         ASR_CHECK_LAUNCH();
-        if ((rc = prj_mm(H, false, ri, N, Wip, F, nullptr, hrow, 2 * F, N, F, 0))) return rc;            // :364
-        if ((rc = prj_mm(H, false, hrow_c, 2 * F, Sm, 12 * N, sb, sc, 12 * N, F, 12 * N, 0))) return rc;  // :367-370
-        if ((rc = prj_mm(H, false, ohprev, 2 * F, Woo, 4 * N, nullptr, a, 4 * N, F, 4 * N, 0))) return rc;  // :376
-        hipLaunchKernelGGL(prj_cell_fwd_kernel<1>, dim3(B, d->ndir), dim3(256), 0, st, A);
+        if ((rc = prj_mm(H, false, rrow, 2 * N, W3, 12 * N, A.p3, N, 12 * N, A.ns_3, -1, 0, 0))) return rc;   // :364-370
+        prj_cell_fwd_launch<1>(A, d->ndir, st);
         ASR_CHECK_LAUNCH();
-        if ((rc = prj_mm(H, false, ro, N, Wop, F, nullptr, ohrow, 2 * F, N, F, 0))) return rc;           // :410
     }
     return ASR_OK;
 }
@@ -340,57 +445,38 @@ extern "C" int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
     if (rc) return rc;
     for (int k = 0; k < d->ndir; ++k) {
         const PrjDir& D = d->dir[k];
-        if (!D.outer_in || !D.Wio || !D.Wi_p || !D.S || !D.Wo_o || !D.Wo_p || !D.ai || !D.bi_c || !D.ao || !D.bo_c ||
-            !D.gi || !D.go || !D.ci || !D.co || !D.xhi || !D.xho || !D.rsi || !D.rso || !D.sc || !D.a || !D.dhid ||
-            !D.dii || !D.doi || !D.dsc || !D.da || !D.dh || !D.douti || !D.douto)
+        if (!D.outer_in || !D.Wf || !D.W3 || !D.ai || !D.bi_c || !D.ao || !D.bo_c || !D.gi || !D.go || !D.ci || !D.co ||
+            !D.xhi || !D.xho || !D.rsi || !D.rso || !D.sc || !D.a || !D.dr || !D.dta || !D.doi || !D.dsc || !D.douti ||
+            !D.douto)
             return ASR_ERR_ARG;
     }
     if (d->T == 0) return ASR_OK;
     PrjHost H;
-    if ((rc = prj_args(d, ws, st, H))) return rc;
+    prj_args(d, ws, st, true, H);
     PrjArgs& A = H.A;
-    const int T = d->T, B = d->B, N = d->N, F = d->F;
-    // carried gradients start at zero (tg is not used backward)
-    if (hipMemsetAsync(A.g_c[0], 0, (size_t)4 * d->ndir * B * N * sizeof(float), st) !=
-        hipSuccess)
-        return ASR_ERR_LAUNCH;
-    // dh starts as dhid (rows of this chunk, every t); each step adds its recurrent part to dh of the step before
-    for (int k = 0; k < d->ndir; ++k) {
-        const PrjDir& D = d->dir[k];
-        if (hipMemcpy2DAsync(D.dh + (size_t)d->b0 * 2 * F, (size_t)d->Btot * 2 * F * sizeof(float),
-                             D.dhid + (size_t)d->b0 * 2 * F, (size_t)d->Btot * 2 * F * sizeof(float),
-                             (size_t)B * 2 * F * sizeof(float), T, hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return ASR_ERR_LAUNCH;
-    }
+    const int T = d->T, B = d->B, N = d->N;
+    const bool zb = (N % 16) == 0;
+    // carried cell gradients start at zero; dr holds the external part (dhid . W_prj^T) of every step on entry
+    if (hipMemsetAsync(A.g_c[0], 0, (size_t)2 * d->ndir * B * N * sizeof(float), st) != hipSuccess) return ASR_ERR_LAUNCH;
     for (int step = T - 1; step >= 0; --step) {
         prj_times(d, A, step);
-        const float *dh_i[2], *dh_o[2], *dsc[2], *dii[2], *da[2];
-        const float *Wio[2], *Wip[2], *Sm[2], *Woo[2], *Wop[2];
-        float *dh_iw[2], *gr0[2], *gr1[2], *gh[2], *gh_o[2];
+        A.first = step == T - 1;
+        const float *dsc[2], *dta[2], *Wf[2], *W3[2];
         for (int k = 0; k < 2; ++k) {
             const int kk = k < d->ndir ? k : 0;
             const PrjDir& D = A.d[kk];
             const size_t row0 = (size_t)A.t[kk] * d->Btot + d->b0;
-            dh_iw[k] = D.dh + row0 * 2 * F; dh_i[k] = dh_iw[k]; dh_o[k] = dh_iw[k] + F;
-            dsc[k] = D.dsc + row0 * 12 * N; dii[k] = D.dii + row0 * 4 * N; da[k] = D.da + row0 * 4 * N;
-            gr0[k] = A.g_r[0] + (size_t)kk * B * N; gr1[k] = A.g_r[1] + (size_t)kk * B * N;
-            gh[k] = D.dh + ((size_t)(A.tp[kk] < 0 ? A.t[kk] : A.tp[kk]) * d->Btot + d->b0) * 2 * F; gh_o[k] = gh[k] + F;
-            Wio[k] = D.Wio; Wip[k] = D.Wi_p; Sm[k] = D.S; Woo[k] = D.Wo_o; Wop[k] = D.Wo_p;
+            dsc[k] = D.dsc + row0 * 12 * N; dta[k] = D.dta + row0 * 8 * N;
+            Wf[k] = D.Wf; W3[k] = D.W3;
         }
-        // d r_out (total) += d outer_hid . W_outer_prj^T
-        if ((rc = prj_mm(H, true, dh_o, 2 * F, Wop, F, nullptr, gr1, N, F, N, 1))) return rc;
         prj_cell_bwd_launch<1>(A, d->ndir, st);
         ASR_CHECK_LAUNCH();
-        // d inner_hid_t += d scale_outer . S^T ; d r_in (total) += d inner_hid . W_inner_prj^T
-        if ((rc = prj_mm(H, true, dsc, 12 * N, Sm, 12 * N, nullptr, dh_iw, 2 * F, 12 * N, F, 1))) return rc;
-        if ((rc = prj_mm(H, true, dh_i, 2 * F, Wip, F, nullptr, gr0, N, F, N, 1))) return rc;
+        // d r_inner,t += d scale_outer . W3^T
+        if ((rc = prj_mm(H, true, dsc, 12 * N, W3, 12 * N, A.pb3, 12 * N, N, A.ns_b3, -1, 0, 0))) return rc;
         prj_cell_bwd_launch<0>(A, d->ndir, st);
         ASR_CHECK_LAUNCH();
-        // d hid_{t-1} (already holding dhid_{t-1}) += d inner gates . Wio^T ; its outer half += da . Wo_o^T
-        if (step > 0) {
-            if ((rc = prj_mm(H, true, dii, 4 * N, Wio, 4 * N, nullptr, gh, 2 * F, 4 * N, 2 * F, 1))) return rc;
-            if ((rc = prj_mm(H, true, da, 4 * N, Woo, 4 * N, nullptr, gh_o, 2 * F, 4 * N, F, 1))) return rc;
-        }
+        // d r_{t-1} (both cells) += [d inner gates | d a] . Wf^T: handed to the cells of the next step processed
+        if (step > 0 && (rc = prj_mm(H, true, dta, 8 * N, Wf, 8 * N, A.pbf, 8 * N, 2 * N, A.ns_bf, zb ? N : -1, 0, 4 * N))) return rc;
     }
     return ASR_OK;
 }

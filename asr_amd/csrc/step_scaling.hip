@@ -424,7 +424,8 @@ static int scal_mm(ScalHost& Hh, bool nt, const float* const A[2], int lda, cons
         const int kk = k < Hh.nd ? k : 0;
         S.p[k].A = A[kk]; S.p[k].W = W[kk]; S.p[k].bias = bias ? bias[kk] : nullptr; S.p[k].C = Cm[kk];
     }
-    S.lda = lda; S.ldw = ldw; S.ldc = ldc; S.Bm = Hh.A.B; S.K = K; S.Nc = Nc; S.beta = beta; S.nsplit = 1;
+    S.lda = lda; S.ldw = ldw; S.ldc = ldc; S.Bm = Hh.A.B; S.K = K; S.Nc = Nc; S.beta = beta; S.nsplit = 0;
+    S.raw = 0; skinny_no_zero_block(S, nt);
     S.part = Hh.part; S.tickets = Hh.tickets;
     return skinny(nt, S, Hh.nd, Hh.st);
 }

@@ -13,10 +13,21 @@
 #define SK_MAXP 2
 #define SK_TICKETS 4096
 #define SK_PART_FLOATS (512 * 1024)
+#ifndef SK_TARGET_WGS
+#define SK_TARGET_WGS 512      // workgroups per launch the reduction axis is split for
+#endif
 struct SkinnyProb { const float* A; const float* W; const float* bias; float* C; };
 struct SkinnyArgs {
     SkinnyProb p[SK_MAXP];
     int lda, ldw, ldc, Bm, K, Nc, beta, nsplit;     // K: reduction length, Nc: output columns
+    // raw != 0: no combine in this launch.  Split sp writes its 16 x Nc partial block to C + sp * 16 * Nc (rows
+    // >= Bm hold zeros) and the NEXT kernel on the stream sums the nsplit blocks in split order while it loads its
+    // inputs (no bias, no beta).  The in-launch combine (tickets, an agent acquire, nsplit dependent round trips
+    // of the last arriver) was about half of a 13 us product at the ProjectionHyper shapes.
+    int raw;
+    // a known zero block of W is skipped: output blocks whose first column (nn) / row of W (nt) is >= zfrom (nn) or
+    // < zfrom (nt) reduce over [zk0, zk1) only; everything else over [0, K)
+    int zfrom, zk0, zk1;
     float* part; unsigned* tickets;
 };
 
@@ -60,7 +71,9 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
     const SkinnyProb& P = S.p[blockIdx.z];
     const int col = blk * 64 + 4 * bl;
     const bool cv = col < S.Nc, rv = bl < S.Bm;
-    const int ngrp = (S.K + 3) >> 2, nsl = 4 * S.nsplit;
+    const bool zb = blk * 64 >= S.zfrom;
+    const int klo = zb ? S.zk0 : 0, khi = zb ? S.zk1 : S.K;
+    const int ngrp = (khi - klo + 3) >> 2, nsl = 4 * S.nsplit;
     const int per = (ngrp + nsl - 1) / nsl;
     const int g0 = ((int)blockIdx.y * 4 + wave) * per;
     const int g1 = min(g0 + per, ngrp);
@@ -72,8 +85,8 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
         float a[8]; f32x4 w[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int k = 4 * (g + s) + q;
-            const bool kv = (g + s) < g1 && k < S.K;
+            const int k = klo + 4 * (g + s) + q;
+            const bool kv = (g + s) < g1 && k < khi;
             a[s] = (kv && rv) ? Ap[k] : 0.f;
             w[s] = (kv && cv) ? *(const f32x4*)(Wp + (size_t)k * S.ldw) : zero;
         }
@@ -89,6 +102,14 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
     if (wave != 0) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
+    if (S.raw) {
+        if (cv) {
+            float* pc = P.C + ((size_t)blockIdx.y * 16 + q * 4) * S.Nc + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *(f32x4*)(pc + (size_t)r * S.Nc) = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        }
+        return;
+    }
     if (!skinny_combine<4>(S, acc, blk, gridDim.x, lane)) return;
     if (cv) {
         const f32x4 bv = P.bias ? *(const f32x4*)(P.bias + col) : zero;
@@ -107,8 +128,8 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
 }
 
 // C[Bm x Nc] = A[Bm x K] . W[Nc x K]^T (+ C if beta); K % 4 == 0, rows 16-byte aligned.  Workgroup = one
-// 16-column output tile; the K axis goes in 64-column chunks (lane (q, bl): 64 contiguous bytes of row bl,
-// MFMA k index q <-> column 16q + 4e + i of the chunk).
+// 16-column output tile; the K axis goes in 64-column chunks (lane (q, bl) reads 16 bytes of row bl per load, the four
+// lanes of a row 64 contiguous bytes: MFMA k index q <-> column 16e + 4q + i of the chunk).
 static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -117,22 +138,24 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     const SkinnyProb& P = S.p[blockIdx.z];
     const int kout = blk * 16 + bl;
     const bool kv = kout < S.Nc, rv = bl < S.Bm;
-    const int nch = (S.K + 63) >> 6, nsl = 4 * S.nsplit;
+    const bool zb = blk * 16 < S.zfrom;
+    const int klo = zb ? S.zk0 : 0, khi = zb ? S.zk1 : S.K;
+    const int nch = (khi - klo + 63) >> 6, nsl = 4 * S.nsplit;
     const int per = (nch + nsl - 1) / nsl;
     const int c0 = ((int)blockIdx.y * 4 + wave) * per;
     const int c1 = min(c0 + per, nch);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc0 = zero, acc1 = zero;
-    const float* Ap = P.A + (size_t)bl * S.lda + 16 * q;
-    const float* Wp = P.W + (size_t)kout * S.ldw + 16 * q;
+    const float* Ap = P.A + (size_t)bl * S.lda + klo + 4 * q;
+    const float* Wp = P.W + (size_t)kout * S.ldw + klo + 4 * q;
     for (int ch = c0; ch < c1; ch += 2) {
         f32x4 av[8], wv[8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int off = (ch + u) * 64 + 4 * e;
-                const bool ok = (ch + u) < c1 && off + 16 * q < S.K;
+                const int off = (ch + u) * 64 + 16 * e;
+                const bool ok = (ch + u) < c1 && klo + off + 4 * q < khi;
                 av[u * 4 + e] = (ok && rv) ? *(const f32x4*)(Ap + off) : zero;
                 wv[u * 4 + e] = (ok && kv) ? *(const f32x4*)(Wp + off) : zero;
             }
@@ -149,6 +172,14 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     __syncthreads();
     if (wave != 0) return;
     f32x4 acc[1] = {red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]};
+    if (S.raw) {
+        if (kv) {
+            float* pc = P.C + ((size_t)blockIdx.y * 16 + q * 4) * S.Nc + kout;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pc[(size_t)r * S.Nc] = acc[0][r];
+        }
+        return;
+    }
     if (!skinny_combine<1>(S, acc, blk, gridDim.x, lane)) return;
     if (kv) {
 #pragma unroll
@@ -162,14 +193,27 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     }
 }
 
-// np problems of one shape (the directions) in one launch
+// splits of the reduction axis for a launch of np problems: every wave keeps at least one full round of loads
+static inline int skinny_nsplit(bool nt, int K, int Nc, int np, int target_wgs) {
+    const int nblk = nt ? (Nc + 15) / 16 : (Nc + 63) / 64;
+    const int maxsplit = nt ? K / 256 : K / 64;
+    int ns = target_wgs / (np * nblk);
+    if (ns > maxsplit) ns = maxsplit;
+    return ns < 1 ? 1 : ns;
+}
+
+// np problems of one shape (the directions) in one launch.  S.nsplit > 0 is the caller's choice (raw mode: its partial
+// buffers are sized for it), S.nsplit <= 0 lets this function choose (in-launch combine only).  S.zfrom must be set (skinny_no_zero_block() for a dense W).
+static inline void skinny_no_zero_block(SkinnyArgs& S, bool nt) { S.zfrom = nt ? 0 : 0x7fffffff; S.zk0 = 0; S.zk1 = 0; }
 static int skinny(bool nt, SkinnyArgs& S, int np, hipStream_t st) {
     const int nblk = nt ? (S.Nc + 15) / 16 : (S.Nc + 63) / 64;
-    const int maxsplit = nt ? S.K / 256 : S.K / 64;
-    int ns = 512 / (np * nblk);
-    if (ns > maxsplit) ns = maxsplit;
-    if (ns < 1 || np * nblk > SK_TICKETS) ns = 1;
-    while (ns > 1 && (size_t)np * nblk * ns * (nt ? 256 : 1024) > SK_PART_FLOATS) --ns;
+    int ns = S.nsplit;
+    if (ns <= 0) {                         // combine inside the launch: bounded by the ticket and partial buffers
+        ns = skinny_nsplit(nt, S.K, S.Nc, np, SK_TARGET_WGS);
+        if (np * nblk > SK_TICKETS) ns = 1;
+        while (ns > 1 && (size_t)np * nblk * ns * (nt ? 256 : 1024) > SK_PART_FLOATS) --ns;
+    }
+    if (ns > 1 && !S.raw && (!S.part || !S.tickets)) return ASR_ERR_ARG;
     S.nsplit = ns;
     if (nt) hipLaunchKernelGGL(skinny_nt_kernel, dim3(nblk, ns, np), dim3(256), 0, st, S);
     else hipLaunchKernelGGL(skinny_nn_kernel, dim3(nblk, ns, np), dim3(256), 0, st, S);

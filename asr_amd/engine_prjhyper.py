@@ -1,7 +1,9 @@
 """ProjectionHyperLSTMLayer pair (libs/lasagne_libs/hyper_layers.py:14-523) on the step-loop HIP path of
-asr_amd/csrc/step_prjhyper.hip.  Host side: the two all-timestep input projections (:316-317) before the
-loop, every parameter gradient and dX as large GEMMs over all T after it (deferred to the side stream
-where nothing below depends on them).  The layer's output fed upward is the OUTER hidden sequence of each
+asr_amd/csrc/step_prjhyper.hip.  Host side: the two all-timestep input projections (:316-317) and the folded
+recurrent matrices (both projections multiplied into their consumers, see the kernel file) before the loop,
+hid = R . W_prj, dX and every parameter gradient as large GEMMs over all T after it (deferred to the side
+stream where nothing below depends on them); the gradients of the folded matrices are un-folded by the product
+rule (exact algebra, checked against the oracle).  The layer's output fed upward is the OUTER hidden sequence of each
 direction (models/gating_hyper_nets.py:150-171); the inner one is kept for `get_inner_hid`.
 Gate vectors stay in the reference's gate-major layout here (no interleave)."""
 import ctypes as C
@@ -120,8 +122,8 @@ class PrjHyperPair(object):
                 self.inner_grad[d] = g
         return costs[0]
 
-    _SAVE = (('gi', 4), ('go', 4), ('ci', 1), ('co', 1), ('ri', 1), ('ro', 1), ('xhi', 1), ('xho', 1), ('sc', 12), ('a', 4))
-    _BWD = (('dii', 4), ('doi', 4), ('dsc', 12), ('da', 4), ('douti', 1), ('douto', 1))
+    _SAVE = (('gi', 4), ('go', 4), ('ci', 1), ('co', 1), ('r', 2), ('xhi', 1), ('xho', 1), ('sc', 12), ('a', 4))
+    _BWD = (('dr', 2), ('dta', 8), ('doi', 4), ('dsc', 12), ('douti', 1), ('douto', 1))
 
     def _desc(self, T, B, mask, backward):
         N, F = self.N, self.F
@@ -133,13 +135,12 @@ class PrjHyperPair(object):
             c = self.ctx['d'][d]
             Dd = desc.dir[d]
             Dd.reverse = 1 if self.reverse[d] else 0
-            for f, key in (('Wio', 'Wio'), ('Wi_p', 'Wip'), ('S', 'S'), ('s', 's'), ('Wo_o', 'Woo'), ('Wo_p', 'Wop'),
-                           ('ai', 'ai'), ('bi_c', 'bic'), ('ao', 'ao'), ('bo_c', 'boc')):
+            for f, key in (('s', 's'), ('ai', 'ai'), ('bi_c', 'bic'), ('ao', 'ao'), ('bo_c', 'boc')):
                 setattr(Dd, f, dp.p(key).data_ptr())
-            for f in ('inner_in', 'outer_in', 'hid', 'rsi', 'rso') + tuple(n for n, _ in self._SAVE):
+            for f in ('inner_in', 'outer_in', 'Wf', 'W3', 'rsi', 'rso') + tuple(n for n, _ in self._SAVE):
                 setattr(Dd, f, c[f].data_ptr())
             if backward:
-                for f in ('dhid', 'dh') + tuple(n for n, _ in self._BWD):
+                for f in tuple(n for n, _ in self._BWD):
                     setattr(Dd, f, c[f].data_ptr())
         return desc
 
@@ -162,14 +163,26 @@ class PrjHyperPair(object):
             c = {}
             c['inner_in'] = ops.gemm(X, dp.p('Wix'), self._buf('iin%d' % d, rows, 4 * N), bias=dp.p('bi'))
             c['outer_in'] = ops.gemm(X, dp.p('Wox'), self._buf('oin%d' % d, rows, 4 * N))
+            # both projections folded into their consumers (step_prjhyper.hip):
+            #   Wf = [[Wip.Wio[:F], 0], [Wop.Wio[F:], Wop.Woo]] (2N,8N),  W3 = Wip.S (N,12N)
+            Wf = self._buf('Wf%d' % d, 2 * N, 8 * N)
+            Wf[:N, 4 * N:].zero_()
+            ops.gemm(dp.p('Wip'), dp.p('Wio')[:F], Wf[:N, :4 * N])
+            ops.gemm(dp.p('Wop'), dp.p('Wio')[F:], Wf[N:, :4 * N])
+            ops.gemm(dp.p('Wop'), dp.p('Woo'), Wf[N:, 4 * N:])
+            c['Wf'] = Wf
+            c['W3'] = ops.gemm(dp.p('Wip'), dp.p('S'), self._buf('W3%d' % d, N, 12 * N))
             c['hid'] = self._buf('hid%d' % d, rows, 2 * F)
             c['rsi'] = self._buf('rsi%d' % d, rows, 1); c['rso'] = self._buf('rso%d' % d, rows, 1)
             for nm, w in self._SAVE:
                 c[nm] = self._buf('%s%d' % (nm, d), rows, w * N)
             ctx['d'].append(c)
         self._run(self._desc(T, B, mask, False), B, False)
-        for d in range(self.ndir):                      # SliceLayer(num_factors:) + ConcatLayer
-            Y[:, d * F:(d + 1) * F].copy_(ctx['d'][d]['hid'][:, F:])
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            ops.gemm(c['r'][:, :N], dp.p('Wip'), c['hid'][:, :F])                  # :364 inner_hid, all T at once
+            ops.gemm(c['r'][:, N:], dp.p('Wop'), c['hid'][:, F:])                  # :410 outer_hid
+            Y[:, d * F:(d + 1) * F].copy_(c['hid'][:, F:])                         # SliceLayer(num_factors:) + ConcatLayer
         return Y
 
     def backward(self, dY, need_dx=True):
@@ -184,15 +197,17 @@ class PrjHyperPair(object):
             else:
                 c['dhid'][:, :F].copy_(self.inner_grad[d]); self.inner_grad[d] = None
             c['dhid'][:, F:].copy_(dY[:, d * F:(d + 1) * F])
-            c['dh'] = self._buf('dh%d' % d, rows, 2 * F)
             for nm, w in self._BWD:
                 c[nm] = self._buf('%s%d' % (nm, d), rows, w * N)
+            dp = self.dirs[d]                           # the external part of d r: d hid . W_prj^T, all T at once
+            ops.gemm(c['dhid'][:, :F], dp.p('Wip'), c['dr'][:, :N], tb=True)
+            ops.gemm(c['dhid'][:, F:], dp.p('Wop'), c['dr'][:, N:], tb=True)
         self._run(self._desc(T, B, mask, True), B, True)
         dX = self._buf('dX', rows, self.D) if need_dx else None
         if need_dx:
             for d, dp in enumerate(self.dirs):
                 c = ctx['d'][d]
-                ops.gemm(c['dii'], dp.p('Wix'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
+                ops.gemm(c['dta'][:, :4 * N], dp.p('Wix'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
                 ops.gemm(c['doi'], dp.p('Wox'), dX, tb=True, beta=1.0)
         with net.deferred():
             self._param_grads(ctx, rows, T, B)
@@ -204,22 +219,34 @@ class PrjHyperPair(object):
         n1 = (T - 1) * B
         for d, dp in enumerate(self.dirs):
             c = ctx['d'][d]
-            hid, dh = c['hid'], c['dh']
+            r, dta, dhid = c['r'], c['dta'], c['dhid']
+            dii = dta[:, :4 * N]
             if not self.reverse[d]:
                 sl_prev, sl_cur = slice(0, n1), slice(B, rows)
             else:
                 sl_prev, sl_cur = slice(B, rows), slice(0, n1)
-            ops.gemm(X, c['dii'], dp.g('Wix'), ta=True)
-            ops.colreduce(c['dii'], dp.g('bi'), rows, 4 * N)
+            ops.gemm(X, dii, dp.g('Wix'), ta=True)
+            ops.colreduce(dii, dp.g('bi'), rows, 4 * N, ldx=8 * N)
             ops.gemm(X, c['doi'], dp.g('Wox'), ta=True)
+            # gradients of the folded matrices, then the product rule back to the reference's factors
+            dWf = self._buf('dWf%d' % d, 2 * N, 8 * N)
             if n1:
-                ops.gemm(hid[sl_prev], c['dii'][sl_cur], dp.g('Wio'), ta=True)
-                ops.gemm(hid[sl_prev][:, F:], c['da'][sl_cur], dp.g('Woo'), ta=True)
+                ops.gemm(r[sl_prev], dta[sl_cur], dWf, ta=True)
             else:                                       # T == 1: no recurrent step ran
-                dp.g('Wio').zero_(); dp.g('Woo').zero_()
-            ops.gemm(c['ri'], dh[:, :F], dp.g('Wip'), ta=True)
-            ops.gemm(c['ro'], dh[:, F:], dp.g('Wop'), ta=True)
-            ops.gemm(hid[:, :F], c['dsc'], dp.g('S'), ta=True)
+                dWf.zero_()
+            dW3 = ops.gemm(r[:, :N], c['dsc'], self._buf('dW3%d' % d, N, 12 * N), ta=True)
+            Wip, Wop, Wio, Woo, S = dp.p('Wip'), dp.p('Wop'), dp.p('Wio'), dp.p('Woo'), dp.p('S')
+            gWip, gWop, gWio = dp.g('Wip'), dp.g('Wop'), dp.g('Wio')
+            ops.gemm(r[:, :N], dhid[:, :F], gWip, ta=True)                         # hid as an output: inner, outer
+            ops.gemm(r[:, N:], dhid[:, F:], gWop, ta=True)
+            ops.gemm(dWf[:N, :4 * N], Wio[:F], gWip, tb=True, beta=1.0)            # Wf[:N,:4N] = Wip.Wio[:F]
+            ops.gemm(Wip, dWf[:N, :4 * N], gWio[:F], ta=True)
+            ops.gemm(dWf[N:, :4 * N], Wio[F:], gWop, tb=True, beta=1.0)            # Wf[N:,:4N] = Wop.Wio[F:]
+            ops.gemm(Wop, dWf[N:, :4 * N], gWio[F:], ta=True)
+            ops.gemm(dWf[N:, 4 * N:], Woo, gWop, tb=True, beta=1.0)                # Wf[N:,4N:] = Wop.Woo
+            ops.gemm(Wop, dWf[N:, 4 * N:], dp.g('Woo'), ta=True)
+            ops.gemm(dW3, S, gWip, tb=True, beta=1.0)                              # W3 = Wip.S
+            ops.gemm(Wip, dW3, dp.g('S'), ta=True)
             ops.colreduce(c['dsc'], dp.g('s'), rows, 12 * N)
             ops.colreduce(c['douti'], dp.g('ai'), rows, N, y=c['xhi'])
             ops.colreduce(c['douti'], dp.g('bic'), rows, N)

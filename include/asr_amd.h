@@ -256,32 +256,31 @@ int asr_hyper_scan_bwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, 
 
 /* ProjectionHyperLSTMLayer (libs/lasagne_libs/hyper_layers.py:14-523; step :319-417, step_masked
  * :419-456): two N-unit cell-LN LSTMP cells coupled through three scale maps of the new inner hid.  First
- * HIP path: the loop over T runs inside the library, one short chain of kernels per step (launch-bound).
+ * HIP path: the loop over T runs inside the library, 2 skinny products + 2 cell kernels per step and pass (the
+ * products leave per-split partial blocks in the workspace, the cell kernel behind them sums them while loading).
  * Gate vectors are gate-major [i|f|c|o] here.  One call handles batch rows [b0, b0+B), B <= 16. */
 typedef struct asr_prjhyper_dir {
     int reverse;
     const float* inner_in;    /* (T,Btot,4N) x.W_in_to_inner + b_inner (:316) */
     const float* outer_in;    /* (T,Btot,4N) x.W_in_to_outer (:317) */
-    const float* Wio;         /* (2F,4N) [W_inner_to_inner ; W_outer_to_inner] */
-    const float* Wi_p;        /* (N,F) W_inner_prj */
-    const float* S;           /* (F,12N) [W_inner_to_in | W_inner_to_outer | W_inner_to_bias] */
+    const float* Wf;          /* (2N,8N) both projections folded into the recurrent products:
+                                 [[W_inner_prj.W_inner_to_inner, 0], [W_outer_prj.W_outer_to_inner, W_outer_prj.W_outer_to_outer]]
+                                 so that [recurrent inner gates | a]_t = [r_inner | r_outer]_{t-1} . Wf (:329-331,:376) */
+    const float* W3;          /* (N,12N) W_inner_prj . [W_inner_to_in | W_inner_to_outer | W_inner_to_bias] (:364-370) */
     const float* s;           /* (12N) */
-    const float* Wo_o;        /* (F,4N) W_outer_to_outer */
-    const float* Wo_p;        /* (N,F) W_outer_prj */
     const float *ai, *bi_c, *ao, *bo_c;   /* cell layer norm alpha / beta (N) */
-    float* hid;               /* (T,Btot,2F) [inner_hid | outer_hid] (:519) */
+    float* r;                 /* (T,Btot,2N) [r_inner | r_outer], r = o*tanh(outcell), masked; hid = r . W_prj after the loop */
     float *gi, *go;           /* (T,Btot,4N) post-activation gates, saved for BPTT */
     float *ci, *co;           /* (T,Btot,N) masked cell state */
-    float *ri, *ro;           /* (T,Btot,N) masked o*tanh(outcell) */
     float *xhi, *xho;         /* (T,Btot,N) normalised cell */
     float *rsi, *rso;         /* (T,Btot) rstd */
     float* sc;                /* (T,Btot,12N) scale_outer */
-    float* a;                 /* (T,Btot,4N) outer_hid_prev . W_outer_to_outer */
-    const float* dhid;        /* backward: (T,Btot,2F) dLoss/d hid */
-    float *dii, *doi;         /* (T,Btot,4N) d inner gate pre-activations ; d outer_input */
+    float* a;                 /* (T,Btot,4N) a = outer_hid_prev . W_outer_to_outer */
+    float* dr;                /* backward: (T,Btot,2N) dhid . W_prj^T (the part of d r_t from outside the loop) on entry;
+                                 work: switched-off rows add what they pass on to the row of the step before */
+    float* dta;               /* (T,Btot,8N) [d inner gate pre-activations | d a] */
+    float* doi;               /* (T,Btot,4N) d outer_input */
     float* dsc;               /* (T,Btot,12N) d scale_outer */
-    float* da;                /* (T,Btot,4N) */
-    float* dh;                /* (T,Btot,2F) total d hid_t */
     float *douti, *douto;     /* (T,Btot,N) clipped d outcell */
 } asr_prjhyper_dir;
 typedef struct asr_prjhyper_desc {
