@@ -76,6 +76,15 @@ def launch_ranks(args, argv):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # a rank that dies leaves the others inside a collective until RCCL's own timeout: watch all of them and end the
+    # rest (exact PIDs) as soon as one has failed.  Rank 0 prints one short line, far below the pipe's buffer.
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
     out0 = procs[0].communicate()[0].decode()
     rcs = [p.wait() for p in procs]
     sys.stdout.write(out0)
@@ -127,6 +136,8 @@ def selftest_cpu(args, rank, world):
     import torch.distributed as dist
     from asr_amd import dp
     from asr_amd.builders import build_deep_hyperlstm
+    if os.environ.get('ASR_BENCH_SELFTEST_FAIL_RANK') == str(rank):     # tests: a rank that dies before the rendezvous
+        sys.exit(3)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)

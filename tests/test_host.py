@@ -377,6 +377,14 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--selftest-cpu'], env=env2,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode != 0 and b'WORLD_SIZE=1' in r.stderr
+    # a rank that dies (here before the rendezvous) ends the run: the launcher stops the ranks still waiting for it
+    # and exits non-zero instead of sitting in the collective's own timeout
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--selftest-cpu', '--steps', '2',
+                        '--warmup', '1'], env=dict(env, ASR_BENCH_SELFTEST_FAIL_RANK='1'), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b'ranks failed' in r.stderr and time.time() - t0 < 60
 
 
 def test_oracle_updaters_known_answers():
