@@ -281,6 +281,48 @@ class LstmPair(object):
     def _buf(self, name, rows, cols, zero=False):
         return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols, zero)
 
+    def prepare(self, train, T, B, mask, cond):
+        """Everything of the forward pass that depends on weights, carried state and the conditioning input only, not on
+        the layer below: the folded / packed recurrent matrices, the window's initial-state snapshot, the LHUC scale
+        factors.  Network.forward() issues it for every layer on the side stream before the first scan starts
+        (Network.prepare_ahead), so that between two scans the main stream carries only the input projection."""
+        net = self.net; N = self.N; P = self.P
+        Pout = P if P else N
+        out = []
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            if P:
+                Wf = self._buf('Wf%d' % d, N, 4 * N)
+                ops.gemm(dp.p('Wp'), dp.p('Wh'), Wf)
+            else:
+                Wf = dp.p('Wh')
+            c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d),
+                                                             _lib.lib().asr_lstm_pack_floats(N, 0)))
+            if train:
+                pm = _lib.lib().asr_lstm_bwd_pack_mode(N, self.ndir, self.ln_kind)
+                c['wpkb'] = ops.lstm_pack(Wf, N, pm, net.arena.get('L%d.wpkb%d' % (self.idx, d),
+                                                                   _lib.lib().asr_lstm_pack_floats(N, pm)))
+            st = self.state[d]
+            if st is not None:           # this window's initial state, kept for its backward pass
+                c['c0'] = self._buf('c0_%d' % d, B, N); c['r0'] = self._buf('r0_%d' % d, B, N)
+                c['c0'].copy_(st[0]); c['r0'].copy_(st[1])
+            if self.kind == 'lhuc':
+                if net.seqsum is not None:                  # SeqSumLHUCLSTMLayer, :487-489
+                    emb = net.seqsum.emb
+                else:
+                    emb = cond[:, 0, :].contiguous()        # IVectorLHUCLSTMLayer, :504-510
+                acts = [emb]
+                for i in range(self.npl):
+                    a = self._buf('lh_a%d_%d' % (i, d), B, self.npu)
+                    ops.gemm(acts[-1], dp.p('We%d' % i), a)
+                    ops.bias_act(a, dp.p('be%d' % i), B, self.npu, 1)
+                    acts.append(a)
+                sf = self._buf('lh_sf%d' % d, B, Pout)
+                ops.gemm(acts[-1], dp.p('We%d' % self.npl), sf, bias=dp.p('be%d' % self.npl))
+                c['acts'] = acts; c['sf'] = sf
+            out.append(c)
+        return out
+
     def forward(self, X, T, B, mask, cond, train):
         net = self.net; N = self.N; P = self.P; rows = T * B
         Pout = P if P else N
@@ -290,8 +332,9 @@ class LstmPair(object):
         desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
         self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, cond=cond, Y=Y, d=[])
+        prep = net.take_prepared(self) or self.prepare(train, T, B, mask, cond)
         for d, dp in enumerate(self.dirs):
-            c = {}
+            c = prep[d]
             xin = self._buf('xin%d' % d, rows, 4 * N)
             if self.kind == 'icond_ln_prj':
                 Tc = cond.shape[1]
@@ -317,17 +360,6 @@ class LstmPair(object):
                 else:
                     ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, pre=c['bt'], pmod=B, amod=B, xhat=xh, rstd=rs)
                 c.update(xhat_in=xh, rs_in=rs)
-            if P:
-                Wf = self._buf('Wf%d' % d, N, 4 * N)
-                ops.gemm(dp.p('Wp'), dp.p('Wh'), Wf)
-            else:
-                Wf = dp.p('Wh')
-            c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d),
-                                                             _lib.lib().asr_lstm_pack_floats(N, 0)))
-            if train:
-                pm = _lib.lib().asr_lstm_bwd_pack_mode(N, self.ndir, self.ln_kind)
-                c['wpkb'] = ops.lstm_pack(Wf, N, pm, net.arena.get('L%d.wpkb%d' % (self.idx, d),
-                                                                   _lib.lib().asr_lstm_pack_floats(N, pm)))
             Dd = desc.dir[d]
             Dd.reverse = 1 if self.reverse[d] else 0
             Dd.xin = xin.data_ptr(); Dd.wpack = c['wpk'].data_ptr()
@@ -338,10 +370,7 @@ class LstmPair(object):
                 Dd.alpha_hid = c['al_hid'].data_ptr()
             if self.cell_ln:
                 Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
-            st = self.state[d]
-            if st is not None:           # this window's initial state, kept for its backward pass
-                c['c0'] = self._buf('c0_%d' % d, B, N); c['r0'] = self._buf('r0_%d' % d, B, N)
-                c['c0'].copy_(st[0]); c['r0'].copy_(st[1])
+            if 'c0' in c:
                 Dd.c0 = c['c0'].data_ptr(); Dd.r0 = c['r0'].data_ptr()
             direct = (not P) and self.kind != 'lhuc'       # scan writes straight into Y's column block
             if direct:
@@ -361,14 +390,18 @@ class LstmPair(object):
                 Dd.chat = c['chat'].data_ptr(); Dd.rs_c = c['rs_c'].data_ptr()
             ctx['d'].append(c)
         net.scan_lstm(self, desc, backward=False)
+        if self.stateful and any(st is not None for st in self.state):
+            with net.deferred():          # the next window's start: not on this window's critical path
+                for d in range(self.ndir):
+                    if self.state[d] is not None:               # libs/lhuclstm_layers.py:313-319
+                        c = ctx['d'][d]
+                        last = T - 1
+                        if self.context:
+                            last = (T if T < self.context else self.context) - 1
+                        self.state[d][0].copy_(c['cst'][last * B:(last + 1) * B])
+                        self.state[d][1].copy_(c['R'][last * B:(last + 1) * B])
         for d, dp in enumerate(self.dirs):
             c = ctx['d'][d]
-            if self.stateful and self.state[d] is not None:     # libs/lhuclstm_layers.py:313-319
-                last = T - 1
-                if self.context:
-                    last = (T if T < self.context else self.context) - 1
-                self.state[d][0].copy_(c['cst'][last * B:(last + 1) * B])
-                self.state[d][1].copy_(c['R'][last * B:(last + 1) * B])
             Yd = Y[:, d * Pout:(d + 1) * Pout]
             if P and self.kind != 'lhuc':
                 ops.gemm(c['R'], dp.p('Wp'), Yd)
@@ -379,20 +412,7 @@ class LstmPair(object):
                 else:
                     hid = c['R']
                 c['hid'] = hid
-                if net.seqsum is not None:                  # SeqSumLHUCLSTMLayer, :487-489
-                    emb = net.seqsum.emb
-                else:
-                    emb = cond[:, 0, :].contiguous()        # IVectorLHUCLSTMLayer, :504-510
-                acts = [emb]
-                for i in range(self.npl):
-                    a = self._buf('lh_a%d_%d' % (i, d), B, self.npu)
-                    ops.gemm(acts[-1], dp.p('We%d' % i), a)
-                    ops.bias_act(a, dp.p('be%d' % i), B, self.npu, 1)
-                    acts.append(a)
-                sf = self._buf('lh_sf%d' % d, B, Pout)
-                ops.gemm(acts[-1], dp.p('We%d' % self.npl), sf, bias=dp.p('be%d' % self.npl))
-                c['acts'] = acts; c['sf'] = sf
-                ops.rowscale(hid, hid.stride(0), sf, B, True, Yd, Yd.stride(0), rows, Pout)
+                ops.rowscale(hid, hid.stride(0), c['sf'], B, True, Yd, Yd.stride(0), rows, Pout)
         return Y
 
     def backward(self, dY, need_dx=True):
@@ -405,6 +425,7 @@ class LstmPair(object):
         rows = T * B
         Pout = P if P else N
         later = []
+        early = []          # parameter gradients that need only dY: side stream, under this layer's own scan
         desc = _lib.LstmScanDesc()
         desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
         desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind, self.cell_ln, self.clip
@@ -416,7 +437,7 @@ class LstmPair(object):
                 sf = c['sf']; hid = c['hid']
                 dhid = self._buf('lh_dhid%d' % d, rows, Pout)
                 ops.rowscale(dYd, dYd.stride(0), sf, B, True, dhid, Pout, rows, Pout)
-                later.append(lambda d=d, dp=dp, c=c, dYd=dYd: self._lhuc_param_grads(d, dp, c, dYd, rows, B, Pout))
+                early.append(lambda d=d, dp=dp, c=c, dYd=dYd: self._lhuc_param_grads(d, dp, c, dYd, rows, B, Pout))
                 dYd = dhid
             if P:
                 dR = self._buf('dR%d' % d, rows, N)
@@ -445,6 +466,10 @@ class LstmPair(object):
                 c['dOut'] = self._buf('dOut%d' % d, rows, N); Dd.dOut = c['dOut'].data_ptr()
             Dd.dr_ext = dR.data_ptr(); Dd.ld_dr = dR.stride(0)
             c['dG'] = self._buf('dG%d' % d, rows, 4 * N); Dd.dG = c['dG'].data_ptr()
+        if early:
+            with net.deferred():
+                for fn in early:
+                    fn()
         net.scan_lstm(self, desc, backward=True)
         dX = self._buf('dX', rows, self.D) if need_dx else None
         for d, dp in enumerate(self.dirs):
@@ -784,6 +809,31 @@ class Network(object):
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
+    def prepare_ahead(self, train, T, B, mask, cond):
+        """Issues every layer's weight-only forward work (pair.prepare) on the side stream, behind everything enqueued
+        so far (the optimiser step that produced the weights), before the first layer's scan starts.  Measured on a
+        TBPTT window of cfg5 under rocprofv3: ~75 us of tiny launches per layer (LHUC scale MLP, packs, state snapshot)
+        sat between two 320 us scans on the main stream; cfg3: the 24 fold products + packs of a HyperLSTM layer."""
+        if not self.overlap:
+            return
+        todo = [p for p in self.pairs if hasattr(p, 'prepare')]
+        if not todo:
+            return
+        with self.deferred():
+            for p in todo:
+                p._prepared = p.prepare(train, T, B, mask, cond)
+                p._prepared_ev = torch.cuda.Event()
+                p._prepared_ev.record()
+
+    def take_prepared(self, pair):
+        """pair.forward(): what prepare_ahead() left for this pair (the main stream then waits for it), or None."""
+        prep = getattr(pair, '_prepared', None)
+        if prep is None:
+            return None
+        pair._prepared = None
+        torch.cuda.current_stream().wait_event(pair._prepared_ev)
+        return prep
+
     # ---- scan launch helpers ------------------------------------------------------------------
     def _workspace(self, key, nbytes):
         ws = self._ws.get(key)
@@ -890,6 +940,7 @@ class Network(object):
         if drop:
             self.dropout_step += 1
         self._drop_ids = []
+        self.prepare_ahead(train, T, B, mask, cond)
         for l, pair in enumerate(self.pairs):
             if drop:
                 act = self._dropout_fwd(l, act)
@@ -907,6 +958,7 @@ class Network(object):
         else:
             ops.gemm(act, self.out.p('W'), logits, bias=self.out.p('b'))   # libs/builder_utils.py:44-45
         self.logits = logits
+        self.join_deferred()       # carried-state copies of stateful layers (side stream) before anything reads the state
         return logits
 
     # the output layer as the consumer of a chunked top layer (same protocol as HyperPair.begin_input)

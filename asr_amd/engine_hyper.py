@@ -123,6 +123,28 @@ class HyperPair(object):
         n = self.net.scan_chunks if (train and T >= 256) else 1
         return chunk_bounds(T, n)
 
+    def prepare(self, train, T, B, mask, cond):
+        """Weight-only forward work (engine.Network.prepare_ahead): the folded matrix M and the packed recurrent
+        slices of both passes, per direction."""
+        net = self.net; N, H = self.N, self.H
+        L = _lib.lib()
+        out = []
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            Mi = self._fold(dp, d)
+            c['Mi'] = Mi
+            for mode, nm in ((0, 'wpk'), (1, 'wpkb')):
+                if mode == 1 and not train:
+                    continue
+                n = L.asr_hyper_pack_floats(N, H, mode)
+                o = net.arena.get('L%d.%s%d' % (self.idx, nm, d), n)
+                check(L.asr_hyper_pack_w(dp.p('Wh').data_ptr(), dp.p('Wxh').data_ptr(), dp.p('Whh').data_ptr(),
+                                         Mi.data_ptr(), N, H, mode, o.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), 'asr_hyper_pack_w')
+                c[nm] = o
+            out.append(c)
+        return out
+
     def forward(self, X, T, B, mask, cond, train, consumer=None):
         net = self.net; N, H = self.N, self.H
         rows = T * B
@@ -135,24 +157,15 @@ class HyperPair(object):
         self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[], train=train)
         fed = self.input_ready
         self.input_ready = False
+        prep = net.take_prepared(self) or self.prepare(train, T, B, mask, cond)
         for d, dp in enumerate(self.dirs):
-            c = {}
+            c = prep[d]
+            Mi = c['Mi']
             if fed:                              # projected piecewise by the layer below (accumulate_input)
                 c['xproj'], c['xhproj'] = self._in[d]
             else:
                 c['xproj'] = ops.gemm(X, dp.p('Wx'), self._buf('xproj%d' % d, rows, 4 * N), bias=self._xbias(dp))
                 c['xhproj'] = ops.gemm(X, dp.p('Wxh')[N:], self._buf('xhproj%d' % d, rows, 4 * H), bias=dp.p('bh'))
-            Mi = self._fold(dp, d)
-            c['Mi'] = Mi
-            for mode, nm in ((0, 'wpk'), (1, 'wpkb')):
-                if mode == 1 and not train:
-                    continue
-                n = L.asr_hyper_pack_floats(N, H, mode)
-                out = net.arena.get('L%d.%s%d' % (self.idx, nm, d), n)
-                check(L.asr_hyper_pack_w(dp.p('Wh').data_ptr(), dp.p('Wxh').data_ptr(), dp.p('Whh').data_ptr(),
-                                         Mi.data_ptr(), N, H, mode, out.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream), 'asr_hyper_pack_w')
-                c[nm] = out
             Dd = desc.dir[d]
             Dd.reverse = 1 if self.reverse[d] else 0
             Dd.xproj = c['xproj'].data_ptr(); Dd.xhproj = c['xhproj'].data_ptr()

@@ -134,6 +134,29 @@ class RecPair(object):
         ops.gemm(s, dp.p('Wbt'), bt, bias=dp.p('b') if v['bias'] else dp.p('bbt'))
         c.update(src=src, pre=pre, s=s, al_in=al_in, al_hid=al_hid, bt=bt, pool=(sb, st, Tc, mode))
 
+    def prepare(self, train, T, B, mask, cond):
+        """Weight-only forward work (engine.Network.prepare_ahead): folded / packed recurrent matrices and, for the
+        classes conditioned on an external input (i-vector), the whole conditioning prologue."""
+        net = self.net; N = self.N; P = self.P; v = self.v
+        L = _lib.lib()
+        out = []
+        for d, dp in enumerate(self.dirs):
+            c = {}
+            if v['cond'] and v['cond'] != 'own':
+                self._cond_fwd(d, dp, c, None, T, B, mask, cond)
+            if P:
+                Wf = self._buf('Wf%d' % d, N, 4 * N)
+                ops.gemm(dp.p('Wp'), dp.p('Wh'), Wf)
+            else:
+                Wf = dp.p('Wh')
+            c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d), L.asr_lstm_pack_floats(N, 0)))
+            if train:
+                pm = L.asr_lstm_bwd_pack_mode(N, self.ndir, self.ln_kind + (2 if self.grp == 4 else 0))
+                c['wpkb'] = ops.lstm_pack(Wf, N, pm, net.arena.get('L%d.wpkb%d' % (self.idx, d),
+                                                                   L.asr_lstm_pack_floats(N, pm)))
+            out.append(c)
+        return out
+
     def forward(self, X, T, B, mask, cond, train):
         net = self.net; N = self.N; P = self.P; v = self.v; rows = T * B
         Pout = P or N
@@ -144,9 +167,10 @@ class RecPair(object):
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
         self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, cond=cond, Y=Y, d=[])
         L = _lib.lib()
+        prep = net.take_prepared(self) or self.prepare(train, T, B, mask, cond)
         for d, dp in enumerate(self.dirs):
-            c = {}
-            if v['cond']:
+            c = prep[d]
+            if v['cond'] == 'own':
                 self._cond_fwd(d, dp, c, X, T, B, mask, cond)
             xin = self._buf('xin%d' % d, rows, 4 * N)
             if self.ln_kind == 0:
@@ -164,16 +188,6 @@ class RecPair(object):
                     ops.ln_rows_fwd(xin, 4 * N, c['al_in'], xin, beta=c['bt'], amod=B, xhat=xh, rstd=rs,
                                     groups=self.grp)
                 c.update(xhat_in=xh, rs_in=rs)
-            if P:
-                Wf = self._buf('Wf%d' % d, N, 4 * N)
-                ops.gemm(dp.p('Wp'), dp.p('Wh'), Wf)
-            else:
-                Wf = dp.p('Wh')
-            c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d), L.asr_lstm_pack_floats(N, 0)))
-            if train:
-                pm = L.asr_lstm_bwd_pack_mode(N, self.ndir, self.ln_kind + (2 if self.grp == 4 else 0))
-                c['wpkb'] = ops.lstm_pack(Wf, N, pm, net.arena.get('L%d.wpkb%d' % (self.idx, d),
-                                                                   L.asr_lstm_pack_floats(N, pm)))
             Dd = desc.dir[d]
             Dd.reverse = 1 if self.reverse[d] else 0
             Dd.xin = xin.data_ptr(); Dd.wpack = c['wpk'].data_ptr()

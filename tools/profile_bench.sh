@@ -16,4 +16,5 @@ timeout -s KILL 240 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv 
 timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfmaraw -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfmaraw.log 2>&1
 find $OUT -name "*.csv" | head -20
 python3 $R/tools/summarize_prof.py $OUT $TAG $R/gpurun_out/prof_summary_$TAG
+python3 $R/tools/timeline_gaps.py $(find $OUT/stats -name "*kernel_trace.csv" | head -1) > $R/gpurun_out/prof_summary_$TAG/${TAG}_bench_timeline.txt 2>&1 || true
 ls -la $R/gpurun_out/prof_summary_$TAG
