@@ -215,6 +215,9 @@ def other_config(args, rank, world, dev):
 
     def step(i):
         b = batches[i % len(batches)]
+        if args.forward_only:       # bin/forward_*.py: log-posteriors of the batch, nothing saved for BPTT
+            net.posteriors(b['x'], b['m'], b['iv'], log=True)
+            return b['frames']
         if cfg != 5:
             net.loss(b['x'], b['m'], b['y'], b['m'], b['iv']); net.backward(); ar.finish(); net.adam_update(1e-3)
             return b['frames']
@@ -247,7 +250,10 @@ def other_config(args, rank, world, dev):
         fsum = tt[1:2].clone(); dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
         dt = tmax.item(); frames = fsum.item()
     if rank == 0:
-        out = dict(metric='train frames/sec (node)', value=frames / dt, unit='frames/s', n_gpus=world,
+        if args.forward_only:
+            name += ' -- FORWARD ONLY (log-posteriors, as bin/forward_*.py)'
+        out = dict(metric='forward frames/sec (node)' if args.forward_only else 'train frames/sec (node)',
+                   value=frames / dt, unit='frames/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
                    data='synthetic', config=dict(workload=name, per_gpu_batch=BATCH,
@@ -273,6 +279,8 @@ def main():
                          'into three bf16 parts (default), f32 = fp32 MFMA throughout, bf16 = the optional bf16 mode')
     ap.add_argument('--bf16', action='store_true', help='same as --precision bf16: reported as dtype bf16-gemm, '
                                                         'never the default')
+    ap.add_argument('--forward-only', action='store_true',
+                    help='with --cfg 1/2/4: time the forward pass alone (BASELINE configs[0] is a forward-only case)')
     ap.add_argument('--selftest-cpu', action='store_true',
                     help='rehearse the N-rank protocol on the CPU over gloo (no kernels; for tests)')
     args = ap.parse_args()

@@ -541,3 +541,63 @@ def test_lhuc_seqsum_tbptt_windows():
         gmax = max(np.max(np.abs(g)) for g in ograds)
         for g, og in zip(net.get_all_grad_values(), ograds):
             assert np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax) < 1e-4
+
+
+@pytest.mark.parametrize('kind', ['hyper', 'ln_prj', 'ivec_cond', 'lhuc_tbptt'])
+def test_work_issued_ahead_on_the_side_stream_changes_no_bit(kind):
+    """Network.prepare_ahead (folds, packs, LHUC scale MLP, external cond-LN prologue, TBPTT state snapshot issued on the
+    side stream before the first scan; carried-state copies behind the scan) against the same net with everything
+    inline on one stream (overlap off): loss and every gradient bit for bit, over two consecutive steps / three
+    TBPTT windows (the second and third start from carried state)."""
+    from asr_amd import builders, gating_hyper_nets as G
+    dev = _dev()
+    I = 0
+    tb = []
+    if kind == 'hyper':
+        net = builders.build_deep_hyperlstm('hyper', None, None, 5, 2, 8, 4, 2, 6, 0.05, True, 0, device=dev, seed=21)
+    elif kind == 'ln_prj':
+        net = G.deep_projection_ln_lstm_model(None, None, 5, 6, 2, None, 8, 0.05, 0.0, device=dev, seed=22)
+    elif kind == 'ivec_cond':
+        net, _ = G.deep_projection_ivector_ln_model(None, None, None, 5, 6, 2, 1, 3, 8, grad_clipping=0.05, dropout=0.0,
+                                                    cond_dim=3, device=dev, seed=23)
+        I = 3
+    else:
+        net, _, tb = builders.build_deep_uni_lhuclstm_ivector_tbptt(
+            'IVectorLHUCLSTMLayer', None, None, 5, 2, 8, 0, 6, 1, 5, 0, 0, 0, 3, 0.05, False, False, 3, True,
+            device=dev, seed=24)
+        I = 3
+    perturb_params(net, 25, 0.15)
+    vals = net.get_all_param_values()
+    b = make_batch(np.random.default_rng(26), 3, 9, 5, 6, lengths=[9, 1, 6], I=I)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x, m, y = t(b['x']), t(b['mask']), t(b['y'])
+    iv = t(b['ivec']) if I else None
+
+    def run(overlap):
+        net.overlap = overlap
+        net.set_all_param_values(vals)
+        net.t_prev = 0; net.m.zero_(); net.v.zero_()
+        out = []
+        if tb:
+            for l in tb:
+                l.reset(3)
+            for w in range(3):
+                sl = slice(3 * w, 3 * w + 3)
+                ce, _, _ = net.loss(x[:, sl].contiguous(), m[:, sl].contiguous(), y[:, sl].contiguous(),
+                                    m[:, sl].contiguous(), iv[:, sl].contiguous(), True, 3)
+                net.backward()
+                out.append((ce.item(), net.store.g.clone()))
+                net.adam_update(1e-2)
+        else:
+            for _ in range(2):
+                ce, _, _ = net.loss(x, m, y, m, iv)
+                net.backward()
+                out.append((ce.item(), net.store.g.clone()))
+                net.adam_update(1e-2)
+        net.check_status()
+        return out
+
+    a, c = run(True), run(False)
+    for (ce1, g1), (ce0, g0) in zip(a, c):
+        assert ce1 == ce0
+        assert torch.equal(g1, g0)
