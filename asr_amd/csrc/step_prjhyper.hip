@@ -58,6 +58,7 @@ struct PrjArgs {
     // pbf = dta_{t+1}.Wf^T (2N: what step t+1 hands to d r_t), pb3 = dsc_t.W3^T (N)
     float *pf[2], *p3[2], *pbf[2], *pb3[2];
     int ns_f, ns_3, ns_bf, ns_b3;
+    int Bpad;                   // rows of a partial block: B rounded up to whole 16-row chunks
     int first;                  // backward: the first step processed (nothing handed over from a later step)
 };
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void prj_cell_fwd_kernel(PrjArgs A) {
     if (tp >= 0) {
         const float* pf = A.pf[dir] + (size_t)b * 8 * N + (OUTER ? 4 * N : 0);
         PART_SUM_BEGIN(A.ns_f)
-            const float* pp = pf + (size_t)sp * 16 * 8 * N;
+            const float* pp = pf + (size_t)sp * A.Bpad * 8 * N;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void prj_cell_fwd_kernel(PrjArgs A) {
     if (OUTER) {
         const float* p3 = A.p3[dir] + (size_t)b * 12 * N;
         PART_SUM_BEGIN(A.ns_3)
-            const float* pp = p3 + (size_t)sp * 16 * 12 * N;
+            const float* pp = p3 + (size_t)sp * A.Bpad * 12 * N;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -226,14 +227,14 @@ __global__ __launch_bounds__(256) void prj_cell_bwd_kernel(PrjArgs A) {
         const float* pb = A.pbf[dir] + (size_t)b * 2 * N + (OUTER ? N : 0);
         PART_SUM_BEGIN(A.ns_bf)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) gr[u] += pw * pb[(size_t)sp * 16 * 2 * N + nn[u]];
+            for (int u = 0; u < NU; ++u) gr[u] += pw * pb[(size_t)sp * A.Bpad * 2 * N + nn[u]];
         PART_SUM_END
     }
     if (!OUTER) {
         const float* pb = A.pb3[dir] + (size_t)b * N;
         PART_SUM_BEGIN(A.ns_b3)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) gr[u] += pw * pb[(size_t)sp * 16 * N + nn[u]];
+            for (int u = 0; u < NU; ++u) gr[u] += pw * pb[(size_t)sp * A.Bpad * N + nn[u]];
         PART_SUM_END
     }
     float dxh[NU], do_[NU];
@@ -296,13 +297,14 @@ static void prj_cell_bwd_launch(const PrjArgs& A, int ndir, hipStream_t st) {
 
 struct asr_prjhyper_desc {      // mirrored in include/asr_amd.h
     int T, B, N, F, ndir;
-    int b0, Btot;               // rows [b0, b0+B) of Btot; B <= 16 per call
+    int b0, Btot;               // rows [b0, b0+B) of Btot; B <= 64 per call
     float grad_clip;
     const float* mask; int mask_stride_b, mask_stride_t;
     PrjDir dir[2];
 };
 
-// splits of the four products (functions of N and ndir only, so the workspace can be sized before the call)
+// splits of the four products (functions of B, N and ndir only, so the workspace can be sized before the call)
+#define PRJ_MAXB 64             // batch rows per call: 4 row chunks of 16 in every launch
 struct PrjSplits { int f, w3, bf, b3; };
 static int prj_target_wgs() {
     static int v = 0;
@@ -313,29 +315,30 @@ static int prj_target_wgs() {
     }
     return v;
 }
-static PrjSplits prj_splits(int N, int ndir) {
-    const int tw = prj_target_wgs();
+static PrjSplits prj_splits(int B, int N, int ndir) {
+    const int tw = prj_target_wgs(), npz = ndir * ((B + 15) / 16);
     PrjSplits s;
-    s.f = skinny_nsplit(false, N, 8 * N, ndir, tw);       // the shorter of the two reduction ranges (zero block)
-    s.w3 = skinny_nsplit(false, N, 12 * N, ndir, tw);
-    s.bf = skinny_nsplit(true, 4 * N, 2 * N, ndir, tw);
-    s.b3 = skinny_nsplit(true, 12 * N, N, ndir, tw);
+    s.f = skinny_nsplit(false, N, 8 * N, npz, tw);        // the shorter of the two reduction ranges (zero block)
+    s.w3 = skinny_nsplit(false, N, 12 * N, npz, tw);
+    s.bf = skinny_nsplit(true, 4 * N, 2 * N, npz, tw);
+    s.b3 = skinny_nsplit(true, 12 * N, N, npz, tw);
     return s;
 }
-static size_t prj_part_floats(int N, int ndir) {
-    const PrjSplits s = prj_splits(N, ndir);
-    const size_t fw = (size_t)s.f * 16 * 8 * N + (size_t)s.w3 * 16 * 12 * N;
-    const size_t bw = (size_t)s.bf * 16 * 2 * N + (size_t)s.b3 * 16 * N;
+static size_t prj_part_floats(int B, int N, int ndir) {
+    const PrjSplits s = prj_splits(B, N, ndir);
+    const size_t bp = (size_t)((B + 15) / 16) * 16;
+    const size_t fw = (size_t)s.f * bp * 8 * N + (size_t)s.w3 * bp * 12 * N;
+    const size_t bw = (size_t)s.bf * bp * 2 * N + (size_t)s.b3 * bp * N;
     return (fw > bw ? fw : bw) * ndir;
 }
 
 extern "C" size_t asr_prjhyper_ws_bytes(int B, int N, int F, int ndir) {
     (void)F;
-    return ((size_t)2 * ndir * B * N + prj_part_floats(N, ndir)) * sizeof(float) + 256;
+    return ((size_t)2 * ndir * B * N + prj_part_floats(B, N, ndir)) * sizeof(float) + 256;
 }
 
 static int prj_check(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes) {
-    if (!d || !ws || d->T < 0 || d->B <= 0 || d->B > 16 || d->N <= 0 || d->F <= 0 || (d->N & 3) || (d->F & 3) ||
+    if (!d || !ws || d->T < 0 || d->B <= 0 || d->B > PRJ_MAXB || d->N <= 0 || d->F <= 0 || (d->N & 3) || (d->F & 3) ||
         d->N > 256 * PRJ_MAXU || d->ndir < 1 || d->ndir > 2 || !d->mask || d->b0 < 0 || d->b0 + d->B > d->Btot ||
         ((uintptr_t)ws & 15))
         return ASR_ERR_ARG;
@@ -360,16 +363,18 @@ static void prj_args(const asr_prjhyper_desc* d, void* ws, hipStream_t st, bool 
     const size_t bn = (size_t)d->ndir * d->B * N;
     A.g_c[0] = p; p += bn; A.g_c[1] = p; p += bn;
     p = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    const PrjSplits s = prj_splits(N, d->ndir);
+    const PrjSplits s = prj_splits(d->B, N, d->ndir);
     A.ns_f = s.f; A.ns_3 = s.w3; A.ns_bf = s.bf; A.ns_b3 = s.b3; A.first = 0;
+    const size_t bp = (size_t)((d->B + 15) / 16) * 16;
+    A.Bpad = (int)bp;
     for (int k = 0; k < 2; ++k) {
         const int kk = k < d->ndir ? k : 0;
         if (!backward) {
-            float* q = p + (size_t)kk * ((size_t)s.f * 16 * 8 * N + (size_t)s.w3 * 16 * 12 * N);
-            A.pf[k] = q; A.p3[k] = q + (size_t)s.f * 16 * 8 * N; A.pbf[k] = A.pb3[k] = nullptr;
+            float* q = p + (size_t)kk * ((size_t)s.f * bp * 8 * N + (size_t)s.w3 * bp * 12 * N);
+            A.pf[k] = q; A.p3[k] = q + (size_t)s.f * bp * 8 * N; A.pbf[k] = A.pb3[k] = nullptr;
         } else {
-            float* q = p + (size_t)kk * ((size_t)s.bf * 16 * 2 * N + (size_t)s.b3 * 16 * N);
-            A.pbf[k] = q; A.pb3[k] = q + (size_t)s.bf * 16 * 2 * N; A.pf[k] = A.p3[k] = nullptr;
+            float* q = p + (size_t)kk * ((size_t)s.bf * bp * 2 * N + (size_t)s.b3 * bp * N);
+            A.pbf[k] = q; A.pb3[k] = q + (size_t)s.bf * bp * 2 * N; A.pf[k] = A.p3[k] = nullptr;
         }
     }
     H.nd = d->ndir; H.st = st;
@@ -401,7 +406,7 @@ static void prj_times(const asr_prjhyper_desc* d, PrjArgs& A, int step) {
     if (d->ndir == 1) { A.t[1] = A.t[0]; A.tp[1] = A.tp[0]; }
 }
 
-// Batches of more than 16 rows are run by the caller in chunks of <= 16 rows (b0 advanced).
+// Batches of more than PRJ_MAXB rows are run by the caller in chunks (b0 advanced).
 extern "C" int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
     int rc = prj_check(d, ws, ws_bytes);
     if (rc) return rc;

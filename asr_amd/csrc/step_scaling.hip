@@ -372,7 +372,7 @@ static void scal_cell_launch(const ScalArgs& A, bool backward, hipStream_t st) {
 
 struct asr_scaling_desc {       // mirrored in include/asr_amd.h
     int T, B, N, H, ndir;
-    int b0, Btot;               // rows [b0, b0+B) of Btot; B <= 16 per call
+    int b0, Btot;               // rows [b0, b0+B) of Btot; B <= 64 per call
     int use_peepholes, use_layer_norm;
     float grad_clip;
     const float* mask; int mask_stride_b, mask_stride_t;
@@ -392,7 +392,7 @@ struct ScalHost {
 };
 
 static int scal_setup(const asr_scaling_desc* d, void* ws, size_t ws_bytes, hipStream_t st, ScalHost& Hh) {
-    if (!d || !ws || d->T < 0 || d->B <= 0 || d->B > 16 || d->N <= 0 || d->H <= 0 || (d->N & 3) || (d->H & 3) ||
+    if (!d || !ws || d->T < 0 || d->B <= 0 || d->B > 64 || d->N <= 0 || d->H <= 0 || (d->N & 3) || (d->H & 3) ||
         d->N > 256 * SC_MAXU || d->H > 256 * SC_MAXU || d->ndir < 1 || d->ndir > 2 || !d->mask || d->b0 < 0 ||
         d->b0 + d->B > d->Btot || ((uintptr_t)ws & 15))
         return ASR_ERR_ARG;
@@ -439,7 +439,7 @@ static void scal_times(const asr_scaling_desc* d, ScalArgs& A, int step) {
     if (d->ndir == 1) { A.t[1] = A.t[0]; A.tp[1] = A.tp[0]; }
 }
 
-// Batches of more than 16 rows are run by the caller in chunks of <= 16 rows (b0 advanced).
+// Batches of more than 64 rows are run by the caller in chunks (b0 advanced); a launch carries every 16-row chunk.
 extern "C" int asr_scaling_fwd(const asr_scaling_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
     ScalHost Hh;
     int rc = scal_setup(d, ws, ws_bytes, st, Hh);

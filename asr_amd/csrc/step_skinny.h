@@ -4,7 +4,8 @@
 #include "scan_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// Skinny products (<= 16 batch rows) of the step, both directions in one launch (blockIdx.z).  They are
+// Skinny products of the step: Bm batch rows in chunks of 16 (one MFMA tile of rows), both directions and every row chunk in
+// one launch (blockIdx.z = direction * nchunk + chunk).  They are
 // L2-latency-bound, so the reduction axis is cut into 4 * nsplit slices: the 4 waves of a workgroup
 // reduce through LDS, the nsplit workgroups of an output block hand their partial blocks over in the
 // launch (cdna_hip_programming.md Guideline 16: 16-byte sc1 stores, vmcnt(0), one ticket atomic; the
@@ -20,8 +21,9 @@ struct SkinnyProb { const float* A; const float* W; const float* bias; float* C;
 struct SkinnyArgs {
     SkinnyProb p[SK_MAXP];
     int lda, ldw, ldc, Bm, K, Nc, beta, nsplit;     // K: reduction length, Nc: output columns
-    // raw != 0: no combine in this launch.  Split sp writes its 16 x Nc partial block to C + sp * 16 * Nc (rows
-    // >= Bm hold zeros) and the NEXT kernel on the stream sums the nsplit blocks in split order while it loads its
+    int nchunk;                                     // row chunks of 16: ceil(Bm / 16)
+    // raw != 0: no combine in this launch.  Split sp writes its partial block of rows to C + (sp * 16 nchunk + row) * Nc
+    // (rows >= Bm hold zeros) and the NEXT kernel on the stream sums the nsplit blocks in split order while it loads its
     // inputs (no bias, no beta).  The in-launch combine (tickets, an agent acquire, nsplit dependent round trips
     // of the last arriver) was about half of a 13 us product at the ProjectionHyper shapes.
     int raw;
@@ -35,7 +37,7 @@ struct SkinnyArgs {
 template <int NV>
 __device__ __forceinline__ bool skinny_combine(const SkinnyArgs& S, f32x4 (&acc)[NV], int blk, int nblk, int lane) {
     if (S.nsplit == 1) return true;
-    const int split = blockIdx.y, prob = blockIdx.z;
+    const int split = blockIdx.y, prob = blockIdx.z;       // prob: (direction, row chunk)
     const unsigned tile_bytes = 64u * NV * 16u;
     const size_t slot = (size_t)(prob * nblk + blk) * S.nsplit;
     __amdgpu_buffer_rsrc_t rs = make_rsrc_(S.part + slot * (64 * NV * 4), (unsigned)S.nsplit * tile_bytes);
@@ -68,9 +70,10 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, bl = lane & 15;
     const int blk = blockIdx.x;
-    const SkinnyProb& P = S.p[blockIdx.z];
+    const SkinnyProb& P = S.p[blockIdx.z / S.nchunk];
+    const int row0 = (blockIdx.z % S.nchunk) * 16;
     const int col = blk * 64 + 4 * bl;
-    const bool cv = col < S.Nc, rv = bl < S.Bm;
+    const bool cv = col < S.Nc, rv = row0 + bl < S.Bm;
     const bool zb = blk * 64 >= S.zfrom;
     const int klo = zb ? S.zk0 : 0, khi = zb ? S.zk1 : S.K;
     const int ngrp = (khi - klo + 3) >> 2, nsl = 4 * S.nsplit;
@@ -79,7 +82,7 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
     const int g1 = min(g0 + per, ngrp);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4] = {zero, zero, zero, zero};
-    const float* Ap = P.A + (size_t)bl * S.lda;
+    const float* Ap = P.A + (size_t)(row0 + bl) * S.lda;
     const float* Wp = P.W + col;
     for (int g = g0; g < g1; g += 8) {
         float a[8]; f32x4 w[8];
@@ -104,7 +107,7 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
     for (int j = 0; j < 4; ++j) acc[j] = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
     if (S.raw) {
         if (cv) {
-            float* pc = P.C + ((size_t)blockIdx.y * 16 + q * 4) * S.Nc + col;
+            float* pc = P.C + ((size_t)blockIdx.y * 16 * S.nchunk + row0 + q * 4) * S.Nc + col;
 #pragma unroll
             for (int r = 0; r < 4; ++r) *(f32x4*)(pc + (size_t)r * S.Nc) = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         }
@@ -115,7 +118,7 @@ static __global__ __launch_bounds__(256) void skinny_nn_kernel(SkinnyArgs S) {
         const f32x4 bv = P.bias ? *(const f32x4*)(P.bias + col) : zero;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = q * 4 + r;
+            const int row = row0 + q * 4 + r;
             if (row < S.Bm) {
                 f32x4* pc = (f32x4*)(P.C + (size_t)row * S.ldc + col);
                 f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
@@ -135,9 +138,10 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, bl = lane & 15;
     const int blk = blockIdx.x;
-    const SkinnyProb& P = S.p[blockIdx.z];
+    const SkinnyProb& P = S.p[blockIdx.z / S.nchunk];
+    const int row0 = (blockIdx.z % S.nchunk) * 16;
     const int kout = blk * 16 + bl;
-    const bool kv = kout < S.Nc, rv = bl < S.Bm;
+    const bool kv = kout < S.Nc, rv = row0 + bl < S.Bm;
     const bool zb = blk * 16 < S.zfrom;
     const int klo = zb ? S.zk0 : 0, khi = zb ? S.zk1 : S.K;
     const int nch = (khi - klo + 63) >> 6, nsl = 4 * S.nsplit;
@@ -146,7 +150,7 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     const int c1 = min(c0 + per, nch);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc0 = zero, acc1 = zero;
-    const float* Ap = P.A + (size_t)bl * S.lda + klo + 4 * q;
+    const float* Ap = P.A + (size_t)(row0 + bl) * S.lda + klo + 4 * q;
     const float* Wp = P.W + (size_t)kout * S.ldw + klo + 4 * q;
     for (int ch = c0; ch < c1; ch += 2) {
         f32x4 av[8], wv[8];
@@ -174,7 +178,7 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     f32x4 acc[1] = {red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]};
     if (S.raw) {
         if (kv) {
-            float* pc = P.C + ((size_t)blockIdx.y * 16 + q * 4) * S.Nc + kout;
+            float* pc = P.C + ((size_t)blockIdx.y * 16 * S.nchunk + row0 + q * 4) * S.Nc + kout;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pc[(size_t)r * S.Nc] = acc[0][r];
         }
@@ -184,7 +188,7 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     if (kv) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = q * 4 + r;
+            const int row = row0 + q * 4 + r;
             if (row < S.Bm) {
                 float* pc = P.C + (size_t)row * S.ldc + kout;
                 *pc = acc[0][r] + (S.beta ? *pc : 0.f);
@@ -207,16 +211,19 @@ static inline int skinny_nsplit(bool nt, int K, int Nc, int np, int target_wgs) 
 static inline void skinny_no_zero_block(SkinnyArgs& S, bool nt) { S.zfrom = nt ? 0 : 0x7fffffff; S.zk0 = 0; S.zk1 = 0; }
 static int skinny(bool nt, SkinnyArgs& S, int np, hipStream_t st) {
     const int nblk = nt ? (S.Nc + 15) / 16 : (S.Nc + 63) / 64;
+    S.nchunk = (S.Bm + 15) / 16;
+    if (S.nchunk < 1) S.nchunk = 1;
+    const int npz = np * S.nchunk;         // (direction, row chunk) pairs: grid z
     int ns = S.nsplit;
     if (ns <= 0) {                         // combine inside the launch: bounded by the ticket and partial buffers
-        ns = skinny_nsplit(nt, S.K, S.Nc, np, SK_TARGET_WGS);
-        if (np * nblk > SK_TICKETS) ns = 1;
-        while (ns > 1 && (size_t)np * nblk * ns * (nt ? 256 : 1024) > SK_PART_FLOATS) --ns;
+        ns = skinny_nsplit(nt, S.K, S.Nc, npz, SK_TARGET_WGS);
+        if (npz * nblk > SK_TICKETS) ns = 1;
+        while (ns > 1 && (size_t)npz * nblk * ns * (nt ? 256 : 1024) > SK_PART_FLOATS) --ns;
     }
     if (ns > 1 && !S.raw && (!S.part || !S.tickets)) return ASR_ERR_ARG;
     S.nsplit = ns;
-    if (nt) hipLaunchKernelGGL(skinny_nt_kernel, dim3(nblk, ns, np), dim3(256), 0, st, S);
-    else hipLaunchKernelGGL(skinny_nn_kernel, dim3(nblk, ns, np), dim3(256), 0, st, S);
+    if (nt) hipLaunchKernelGGL(skinny_nt_kernel, dim3(nblk, ns, npz), dim3(256), 0, st, S);
+    else hipLaunchKernelGGL(skinny_nn_kernel, dim3(nblk, ns, npz), dim3(256), 0, st, S);
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }

@@ -319,11 +319,11 @@ class ScalingStepPair(object):
     def _run(self, desc, B, backward):
         import ctypes as C
         L = _lib.lib()
-        need = L.asr_scaling_ws_bytes(min(B, 16), self.N, self.H, self.ndir)
+        need = L.asr_scaling_ws_bytes(min(B, 64), self.N, self.H, self.ndir)
         ws = self.net._workspace(('scaling', self.idx), need)
         fn = L.asr_scaling_bwd if backward else L.asr_scaling_fwd
-        for b0 in range(0, B, 16):                      # batch rows are independent: chunks of <= 16 rows
-            desc.b0 = b0; desc.B = min(16, B - b0)
+        for b0 in range(0, B, 64):                      # batch rows are independent: <= 64 rows per call
+            desc.b0 = b0; desc.B = min(64, B - b0)
             check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
                   'asr_scaling_%s' % ('bwd' if backward else 'fwd'))
 

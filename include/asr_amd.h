@@ -258,7 +258,8 @@ int asr_hyper_scan_bwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, 
  * :419-456): two N-unit cell-LN LSTMP cells coupled through three scale maps of the new inner hid.  First
  * HIP path: the loop over T runs inside the library, 2 skinny products + 2 cell kernels per step and pass (the
  * products leave per-split partial blocks in the workspace, the cell kernel behind them sums them while loading).
- * Gate vectors are gate-major [i|f|c|o] here.  One call handles batch rows [b0, b0+B), B <= 16. */
+ * Gate vectors are gate-major [i|f|c|o] here.  One call handles batch rows [b0, b0+B), B <= 64 (every launch carries
+ * all 16-row chunks of both directions). */
 typedef struct asr_prjhyper_dir {
     int reverse;
     const float* inner_in;    /* (T,Btot,4N) x.W_in_to_inner + b_inner (:316) */
@@ -298,7 +299,7 @@ int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, asr_
  * step :963-1095, step_masked :1097-1118, initial rows :1127-1131, scan :1182-1194).  Without options the layer runs on
  * asr_hyper_scan_* (clip_outcell = 1); per-gate layer norms need five all-unit reductions per cell and step, so this
  * path is a step loop inside the library like asr_prjhyper_*: one workgroup per (batch row, direction) runs a cell.
- * Gate vectors gate-major [i|f|c|o]; hid = [inner_hid | outer_hid].  One call handles batch rows [b0, b0+B), B <= 16. */
+ * Gate vectors gate-major [i|f|c|o]; hid = [inner_hid | outer_hid].  One call handles batch rows [b0, b0+B), B <= 64. */
 typedef struct asr_scaling_dir {
     int reverse;
     const float* inner_in;    /* (T,Btot,4H) x.W_inner_in_to_inner + b_inner (:951) */

@@ -68,7 +68,7 @@ def test_c_abi_errors():
         setattr(ld.dir[0], k, x.data_ptr())
     assert L.asr_lstm_scan_fwd(C.byref(ld), ws.data_ptr(), 16, None) == -3
     pd = _lib.PrjHyperDesc()
-    pd.T, pd.B, pd.N, pd.F, pd.ndir, pd.Btot = 4, 17, 8, 4, 1, 17     # more than 16 rows in one call
+    pd.T, pd.B, pd.N, pd.F, pd.ndir, pd.Btot = 4, 65, 8, 4, 1, 65     # more than 64 rows in one call
     pd.mask = m.data_ptr()
     assert L.asr_prjhyper_fwd(C.byref(pd), ws.data_ptr(), ws.numel(), None) == -1
     pd.B = 2; pd.F = 6                                                # F % 4 != 0

@@ -309,6 +309,20 @@ def test_scaling_hyper_options_small(peep, ln, li, clip):
     run_case(net, b)
 
 
+def test_step_loop_layers_more_rows_than_one_call():
+    """B = 67: the step-loop layers take 64 rows per C-ABI call (four 16-row chunks in every launch), the caller loops
+    over calls: one call of 64 rows and one of 3."""
+    from asr_amd.gating_hyper_nets import deep_scaling_hyper_model, deep_projection_hyper_model
+    b = make_batch(np.random.default_rng(57), 67, 3, 5, 6)
+    net = deep_scaling_hyper_model(None, None, 5, 6, [4], [8], use_peepholes=True, use_layer_norm=True, learn_init=True,
+                                   grad_clipping=0.05, device=_dev(), seed=58)
+    perturb_params(net, 59, 0.15)
+    run_case(net, b)
+    net = deep_projection_hyper_model(None, None, 5, 6, 2, 4, 8, grad_clipping=0.05, device=_dev(), seed=60)[0]
+    perturb_params(net, 61, 0.15)
+    run_case(net, b)
+
+
 def test_scaling_hyper_options_timit_script_shape():
     """The configuration scripts/timit/exp_scalehyper.py runs (:26-41,:331-338): one bidirectional layer, 64 inner /
     128 outer units, layer norm and learned initial rows, 123 inputs, 63 classes; 18 rows = two batch chunks; the
