@@ -167,11 +167,11 @@ static inline bool scan_grid_fits(size_t nwg, size_t lds) {
 // ---- optional in-kernel phase stamps (diagnostic build only: -DSCAN_STAMPS; never in the product .so)
 #define STAMP_BYTES 65536
 #ifdef SCAN_STAMPS
-#define STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+#define STAMP_DECL unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #define STAMP(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_prev; st_prev = n_; } while (0)
 #define STAMP_DUMP(ptr, wg) do { if (threadIdx.x == 0 && (ptr) && (wg) < 512) { \
-    _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) (ptr)[(size_t)(wg) * 12 + i_] = st_acc[i_]; } } while (0)
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) (ptr)[(size_t)(wg) * 16 + i_] = st_acc[i_]; } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i) do { } while (0)

@@ -15,11 +15,11 @@ for it in range(2):
     net.loss(x, m, y, m); net.backward()
 net.check_status()
 L = _lib.lib()
-for bw, names in ((False, ['wait_h', 'ph1_mfma', 'epi_hyper', 'publish1', 'wait_hh', 'ph2_mfma', 'epi_main', 'publish2', '-', '-', '-', '-']),
-                  (True, ['S1_main', 'S2_mfma', 'publish1', 'wait1', 'S3_gather', 'S4_hyper', 'publish2', 'wait2', 'S5_mfma', 'prefetch', 'da_mfma', 'bulk_st'])):
+for bw, names in ((False, ['wait_h', 'ph1_mfma', 'epi_hyper', 'publish1', 'wait_hh', 'ph2_mfma', 'epi_main', 'publish2', '-', '-', '-', '-', '-', '-', '-', '-']),
+                  (True, ['S1_main', 'S2_mfma', 'publish1', 'wait1', 'S3_gather', 'S4_hyper', 'publish2', 'wait2', 'S5_tail', 'prefetch', 'da_store', 'bulk_st', 'da_mfma', 'S5_ld_mfma', 'S5_lds_bar', 'S3_dhx'])):
     need = L.asr_hyper_scan_ws_bytes(T, 16, 512, 128, 2, int(bw))
     ws = net._ws[('hyper', 0, bw)]
-    raw = ws[need - 65536:need].view(torch.int64).cpu().numpy()[:256 * 12].reshape(256, 12)
+    raw = ws[need - 65536:need].view(torch.int64).cpu().numpy()[:256 * 16].reshape(256, 16)
     per_step = raw / T
     tot = per_step.sum(1)
     print('backward' if bw else 'forward', 'T=%d cycles/step median over WGs = %.0f (%.2f us @2.1GHz)' % (T, np.median(tot), np.median(tot) / 2100))
