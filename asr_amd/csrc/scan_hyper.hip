@@ -735,6 +735,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc += v[i];
             }
+            STAMP(15);
 #pragma unroll
             for (int i = 0; i < DAB; ++i)
                 dav[i] = ldb_sc1_f4(dax_rs, (unsigned)(lane * 16), da_sbase + (unsigned)(i * 1024));
@@ -800,6 +801,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                     for (int e = 0; e < 4; ++e) acc = mfma4(dv[e], wt[e], acc);
                 }
             }
+            STAMP(12);
             // tile [unit bl][batch q*4..q*4+3] of this wave
             st_sc1_f4(px_rs, (unsigned)(((((size_t)par * G + j) * 4 + wv) * 256 + bl * 16 + q * 4) * 4), acc);
         }
@@ -844,11 +846,13 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
                     }
                 }
             }
+            STAMP(13);
             *(f32x4*)(red + ((size_t)wave * 64 + lane) * 4) = acc;
         }
         if (pc5 / KQ >= R) pv5 = f32x4{0, 0, 0, 0};
         *(f32x4*)(rsum + ((size_t)pc5 * 16 + f45) * 4) = pv5;
         __syncthreads();
+        STAMP(14);
         // output rows i = q*4+reg: i<4 -> main unit i (lanes q==0, reg=i); i=4+uh -> hyper (q==1, reg=uh)
         if (wave == 0) {
             float v = 0.f;

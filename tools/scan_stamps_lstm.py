@@ -20,7 +20,7 @@ for bw, names in ((False, ['wait_r', 'mfma', 'xchg_gateLN', 'gates', 'xchg_cellL
     need = L.asr_lstm_scan_ws_bytes(T, 16, 512, 2, int(bw))
     key = [k for k in net._ws.keys() if k[0] == 'lstm' and k[-1] == bw][0]
     ws = net._ws[key]
-    raw = ws[need - 65536:need].view(torch.int64).cpu().numpy()[:256 * 12].reshape(256, 12)
+    raw = ws[need - 65536:need].view(torch.int64).cpu().numpy()[:256 * 16].reshape(256, 16)
     per_step = raw / T
     tot = per_step.sum(1)
     print('backward' if bw else 'forward', 'T=%d cycles/step median over WGs = %.0f (%.2f us @2.1GHz)' % (T, np.median(tot), np.median(tot) / 2100))
