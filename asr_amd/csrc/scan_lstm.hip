@@ -1150,6 +1150,13 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
         group_publish(gs);
         if (own && bvalid) *(f32x4*)q_dg = dg4;
         if (!group_wait(gs)) break;
+        // the all-gathered dah of this member's column slice is requested BEFORE the statistics are combined: both are
+        // fresh hand-off reads (one fabric round trip each) and do not depend on each other
+        f32x4 dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dv[i] = ldb_sc1_f4(dhx_rs, (unsigned)((bl * 16 + q * 4) * 4),
+                               (unsigned)((((size_t)par * KS + kr * (KS / L2D_R) + wv * TW + (i < TW ? i : 0)) * 256) * 4));
         f32x4 m1, m2;                                    // per gate = per column % 4 = per element of a lane's group
         if (!PG) {
             float s1, s2;
@@ -1164,11 +1171,6 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
         const f32x4 da4 = rs_a * (dah - m1 - ah4 * m2);                  // own columns (owner wave)
         // 4. partial dr_{t-1} of the block's 32 units over this member's column slice
         if (step + 1 < T) {
-            f32x4 dv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                dv[i] = ldb_sc1_f4(dhx_rs, (unsigned)((bl * 16 + q * 4) * 4),
-                                   (unsigned)((((size_t)par * KS + kr * (KS / L2D_R) + wv * TW + (i < TW ? i : 0)) * 256) * 4));
             f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
