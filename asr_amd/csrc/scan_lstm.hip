@@ -1168,7 +1168,14 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
             combine_sums4(sta + (size_t)par * KS * 128, KS, tid, s14, s24, scr);
             m1 = s14 * (1.0f / N); m2 = s24 * (1.0f / N);
         }
-        const f32x4 da4 = rs_a * (dah - m1 - ah4 * m2);                  // own columns (owner wave)
+        // own columns (owner wave).  The value is pinned HERE: left alone, hipcc sinks the whole expression to the store
+        // at the end of the step (after the third publish), and that build gave, about once per launch, a dA whose
+        // ah4*m2 term was missing in gates 0 and 2 of one unit over all 16 batch rows (the low halves of the two
+        // v_pk_fma_f32 ... op_sel:[0,1,0] it used there); every input of the expression was bit-stable.  The instruction
+        // form alone is exact (tools/ubench/pk_opsel.hip, 5e10 results), so the cause is not established; with the value
+        // computed here tools/soak_determinism.py finds no differing bit.
+        f32x4 da4 = rs_a * (dah - m1 - ah4 * m2);
+        asm volatile("" : "+v"(da4[0]), "+v"(da4[1]), "+v"(da4[2]), "+v"(da4[3]));
         // 4. partial dr_{t-1} of the block's 32 units over this member's column slice
         if (step + 1 < T) {
             f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};

@@ -1,0 +1,55 @@
+"""Soak: the same batch through loss + backward many times; every repetition must reproduce the first one's loss and flat
+gradient BIT FOR BIT.  The persistent scans hand data between workgroups inside a launch while parameter-gradient GEMMs run
+beside them on the side stream (uneven load): a stale or torn hand-off read would show as a differing bit here.
+  python tools/soak_determinism.py [reps]"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from asr_amd import builders, gating_hyper_nets as G, workloads
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+dev = 'cuda:0'
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+cases = [
+    ('cfg3 4x512 HyperLSTM', 3, lambda: builders.build_deep_hyperlstm('hyper', None, None, 123, 4, 512, 128, 64, 3436, 1.0, True, 0,
+                                                                       device=dev, seed=1), reps),
+    ('cfg2 4x512 LN-LSTMP', 2, lambda: G.deep_projection_ln_lstm_model(None, None, 123, 3436, 4, None, 512, 1.0, 0.0, device=dev,
+                                                                       seed=1), reps),
+    ('cfg4 i-vector cond-LN', 4, lambda: G.deep_projection_ivector_ln_model(None, None, None, 123, 4174, 4, 4, 64, 512, 1.0, 0.0,
+                                                                            cond_dim=100, device=dev, seed=1)[0], reps),
+    ('cfg1 3x256 LSTM', 1, lambda: builders.build_deep_lstm(None, None, 123, 3, 256, 0, 61, 1.0, True, False, 0, device=dev,
+                                                            seed=1), 4 * reps),
+]
+bad = 0
+for name, cfg, mk, n in cases:
+    net = mk()
+    b = workloads.make_batch(cfg, 16)
+    x, m, y = t(b['x']), t(b['mask']), t(b['y'])
+    iv = t(b['ivec']) if 'ivec' in b else None
+    ref_g = None
+    t0 = time.time()
+    diff = 0
+    for r in range(n):
+        ce, _, _ = net.loss(x, m, y, m, iv)
+        net.backward()
+        g = net.store.g
+        if ref_g is None:
+            torch.cuda.synchronize()
+            ref_g = g.clone(); ref_ce = ce.clone(); ref_lg = net.logits.clone()
+        elif not (torch.equal(g, ref_g) and torch.equal(ce, ref_ce)):
+            diff += 1
+            if diff <= 3:
+                d = (g - ref_g).abs()
+                i = int(d.argmax())
+                print('   rep %d: ce %s (%.9g vs %.9g), max |dg| %.3e at %d of %d (|g| max %.3e), %d elements differ, logits equal: %s'
+                      % (r, 'equal' if torch.equal(ce, ref_ce) else 'DIFFERS', float(ce), float(ref_ce), float(d.max()), i,
+                         g.numel(), float(ref_g.abs().max()), int((d > 0).sum()), torch.equal(net.logits, ref_lg)), flush=True)
+    torch.cuda.synchronize()
+    net.check_status()
+    bad += diff
+    print('%-24s %4d repetitions, %d differ from the first (%.1f s)' % (name, n, diff, time.time() - t0), flush=True)
+    del net
+    torch.cuda.empty_cache()
+print('SOAK', 'FAILED' if bad else 'ok')
+sys.exit(1 if bad else 0)
