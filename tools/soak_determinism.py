@@ -20,18 +20,39 @@ cases = [
                                                                             cond_dim=100, device=dev, seed=1)[0], reps),
     ('cfg1 3x256 LSTM', 1, lambda: builders.build_deep_lstm(None, None, 123, 3, 256, 0, 61, 1.0, True, False, 0, device=dev,
                                                             seed=1), 4 * reps),
+    # windows 1..: stateful layers reset before every repetition, first TBPTT window of the batch
+    ('cfg5 LHUC TBPTT window', 5, lambda: builders.build_deep_uni_lhuclstm_ivector_tbptt(
+        'IVectorLHUCLSTMLayer', None, None, 123, 4, 512, 0, 3436, 1, 128, 0, 0, 0, 16, 1.0, False, False, 100, True,
+        device=dev, seed=1)[0], reps),
+    # the step-loop layers (step_prjhyper.hip, step_scaling.hip), time axis cut to 200 frames
+    ('ProjectionHyper 3x512', 3, lambda: G.deep_projection_hyper_model(None, None, 123, 3436, 3, 256, 512, grad_clipping=1.0,
+                                                                       device=dev, seed=1)[0], max(reps // 4, 4)),
+    ('ScalingHyper options', 1, lambda: G.deep_scaling_hyper_model(None, None, 123, 61, [64], [128], use_layer_norm=True,
+                                                                   learn_init=True, use_peepholes=True, grad_clipping=1.0,
+                                                                   device=dev, seed=1), max(reps // 4, 4)),
+    ('ScalingHyper scan 250/500', 1, lambda: G.deep_scaling_hyper_model(None, None, 123, 61, [250, 250], [500, 500],
+                                                                        grad_clipping=1.0, device=dev, seed=1), reps),
 ]
 bad = 0
 for name, cfg, mk, n in cases:
     net = mk()
-    b = workloads.make_batch(cfg, 16)
+    steploop = name.startswith(('ProjectionHyper', 'ScalingHyper options'))
+    b = workloads.make_batch(cfg, 16, max_len=200 if steploop else None)
     x, m, y = t(b['x']), t(b['mask']), t(b['y'])
     iv = t(b['ivec']) if 'ivec' in b else None
+    tb = net.tbptt_layers()
+    if tb:                                        # one window of 100 frames
+        x, m, y, iv = (a[:, :100].contiguous() for a in (x, m, y, iv))
     ref_g = None
     t0 = time.time()
     diff = 0
     for r in range(n):
-        ce, _, _ = net.loss(x, m, y, m, iv)
+        if tb:
+            for l in tb:
+                l.reset(16)
+            ce, _, _ = net.loss(x, m, y, m, iv, True, 100)
+        else:
+            ce, _, _ = net.loss(x, m, y, m, iv)
         net.backward()
         g = net.store.g
         if ref_g is None:
