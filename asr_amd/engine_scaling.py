@@ -55,6 +55,9 @@ class ScalingPair(object):
         self.net = net; self.idx = idx
         self.D, self.N, self.H = D, N, H
         self.Hp = (H + 3) // 4 * 4
+        if N % 4 or self.Hp > N:
+            raise ValueError('asr_amd: ScalingHyperLSTMLayer needs outer units divisible by 4 and inner units (padded to a '
+                             'multiple of 4: %d) not above the outer units (%d): a limit of the hyper scan' % (self.Hp, N))
         self.clip = float(clip); self.ndir = ndir
         self.out_dim = ndir * N
         self.dirs = [_mk_scaling(net.store, 'L%d.%d.' % (idx, d), D, N, H, self.Hp) for d in range(ndir)]
