@@ -258,6 +258,7 @@ class ScalingStepPair(object):
         self.out_dim = ndir * N
         self.dirs = [_mk_scaling_step(net.store, 'L%d.%d.' % (idx, d), D, N, H, self.peep, self.ln, self.learn_init)
                      for d in range(ndir)]
+        self.kdirs = self.dirs               # what the kernels and the gradient products see (EqualScaleStepPair folds)
         self.reverse = [False, True][:ndir]
         self.inner_grad = [None] * ndir
 
@@ -302,7 +303,7 @@ class ScalingStepPair(object):
         desc.use_peepholes, desc.use_layer_norm = int(self.peep), int(self.ln)
         desc.grad_clip = self.clip
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
-        for d, dp in enumerate(self.dirs):
+        for d, dp in enumerate(self.kdirs):
             c = self.ctx['d'][d]
             Dd = desc.dir[d]
             Dd.reverse = 1 if self.reverse[d] else 0
@@ -335,7 +336,7 @@ class ScalingStepPair(object):
         rows = T * B
         Y = self._buf('Y', rows, self.out_dim)
         self.ctx = ctx = dict(X=X, T=T, B=B, mask=mask, Y=Y, d=[])
-        for d, dp in enumerate(self.dirs):
+        for d, dp in enumerate(self.kdirs):
             c = {}
             c['inner_in'] = ops.gemm(X, dp.p('Wix'), self._buf('iin%d' % d, rows, 4 * H), bias=dp.p('bi'))
             c['outer_in'] = ops.gemm(X, dp.p('Wox'), self._buf('oin%d' % d, rows, 4 * N))
@@ -366,7 +367,7 @@ class ScalingStepPair(object):
         self._run(self._desc(T, B, mask, True), B, True)
         dX = self._buf('dX', rows, self.D) if need_dx else None
         if need_dx:
-            for d, dp in enumerate(self.dirs):
+            for d, dp in enumerate(self.kdirs):
                 c = ctx['d'][d]
                 ops.gemm(c['dgi'], dp.p('Wix'), dX, tb=True, beta=0.0 if d == 0 else 1.0)
                 ops.gemm(c['dgo'], dp.p('Wox'), dX, tb=True, beta=1.0)
@@ -378,7 +379,7 @@ class ScalingStepPair(object):
         N, H = self.N, self.H
         X = ctx['X']
         n1 = (T - 1) * B
-        for d, dp in enumerate(self.dirs):
+        for d, dp in enumerate(self.kdirs):
             c = ctx['d'][d]
             hid = c['hid']
             if not self.reverse[d]:
@@ -412,3 +413,141 @@ class ScalingStepPair(object):
                 ops.colreduce(c['dy_i'], dp.g('lnb_i').view(-1), rows, 5 * H)
                 ops.colreduce(c['dy_o'], dp.g('lna_o').view(-1), rows, 5 * N, y=c['xh_o'])
                 ops.colreduce(c['dy_o'], dp.g('lnb_o').view(-1), rows, 5 * N)
+
+
+# ------------------------------------------------------------------------------------------------
+# EqualScaleHyperLSTMLayer (libs/lasagne_libs/hyper_layers.py:1207-1890)
+# ------------------------------------------------------------------------------------------------
+def _mk_equal_scale(store, prefix, D, N, H, peep, ln):
+    """Store tensors in the reference's shapes (gate-major concatenations) and the reference parameters as views of them,
+    in the add_param order of specs.equal_scale_hyper_params.  U = N is the inner cell's width, H the projected one."""
+    NS = 4 if peep else 3
+    U = N
+    dp = DirParams(store, prefix)
+    dp.add('Wix', (D, 4 * U)); dp.add('Whh', (H, 4 * U)); dp.add('Woi', (N, 4 * U)); dp.add('bi', (4 * U,))
+    if peep:
+        dp.add('wpeep', (4 * U,))
+    if ln:
+        dp.add('lna_i', (5, U)); dp.add('lnb_i', (5, U))
+    dp.add('P', (U, H))
+    dp.add('Wox', (D, 4 * N)); dp.add('Woo', (N, 4 * N)); dp.add('S', (H, NS * 4 * N)); dp.add('s', (NS * 4 * N,))
+    if ln:
+        dp.add('lna_o', (5, N)); dp.add('lnb_o', (5, N))
+    cb = lambda k, w: (lambda E: E[:, k * w:(k + 1) * w])
+    vb = lambda k, w: (lambda E: E[k * w:(k + 1) * w])
+    row = lambda k: (lambda E: E[k])
+    table = {'W_inner_hid_prj': ('P', lambda E: E)}
+    for g, gn in enumerate(G4):
+        table['W_inner_in_to_inner_' + gn] = ('Wix', cb(g, U))
+        table['W_inner_hid_to_inner_' + gn] = ('Whh', cb(g, U))
+        table['W_outer_hid_to_inner_' + gn] = ('Woi', cb(g, U))
+        table['W_inner_cell_to_inner_' + gn] = ('wpeep', vb(g, U))
+        table['b_inner_' + gn] = ('bi', vb(g, U))
+        table['W_outer_in_to_outer_' + gn] = ('Wox', cb(g, N))
+        table['W_outer_hid_to_outer_' + gn] = ('Woo', cb(g, N))
+        for m, mn in enumerate(_MAPS):
+            table['W_inner_hid_to_outer_%s_%s' % (mn, gn)] = ('S', cb(4 * m + g, N))
+            table['b_inner_hid_to_outer_%s_%s' % (mn, gn)] = ('s', vb(4 * m + g, N))
+    for k, gn in enumerate(_LN5):
+        table['W_inner_ln_' + gn] = ('lna_i', row(k)); table['b_inner_ln_' + gn] = ('lnb_i', row(k))
+        table['W_outer_ln_' + gn] = ('lna_o', row(k)); table['b_outer_ln_' + gn] = ('lnb_o', row(k))
+    for name, _, _ in specs.equal_scale_hyper_params(D, H, N, peep, ln, False):
+        key, fn = table[name]
+        dp.map(name, key, 'fn', fn)
+    return dp
+
+
+class _FoldedDir(object):
+    """One direction as asr_scaling_* and ScalingStepPair's gradient products see it: `Wio` and `S` are the folded
+    products (scratch, rebuilt every forward), their gradients scratch as well; everything else is the store's."""
+    def __init__(self, dp):
+        self.dp = dp
+        self.fold = {}; self.gfold = {}
+
+    def p(self, k):
+        return self.fold[k] if k in self.fold else self.dp.p(k)
+
+    def g(self, k):
+        return self.gfold[k] if k in self.gfold else self.dp.g(k)
+
+    def has(self, k):
+        return k in ('Wio', 'S') or self.dp.has(k)
+
+
+class EqualScaleStepPair(ScalingStepPair):
+    """EqualScaleHyperLSTMLayer pair (hyper_layers.py:1207-1890) on the ScalingHyperLSTMLayer step loop
+    (asr_scaling_fwd/bwd).  The layer is ScalingHyperLSTMLayer's step with an inner cell of U = num_outer_units columns
+    per gate whose output u_t = sigmoid(outgate)*tanh(outcell) is projected, h_in = u_t.P (P = W_inner_hid_prj, U x H),
+    before it is carried (:1709).  h_in only ever enters products, and the masked carry is linear in it, so the projection
+    folds into its consumers:  h_in.W_inner_hid_to_inner = u.(P.W_hh)  (:1657),  h_in.[scale maps] = u.(P.S)  (:1714-1717).
+    The kernels therefore run a ScalingHyperLSTMLayer of inner width U with the folded weights; the inner hidden sequence
+    is one GEMM after the loop, and the factors' gradients come from the folded ones by the product rule:
+      dW_hh = P^T.dA,  dS = P^T.dS',  dP = dA.W_hh^T + dS'.S^T (+ u^T.d h_in of an outside consumer).
+    learn_init is not built: inner_hid_init lives in the projected space and has no pre-image under the fold."""
+    kind = 'equalscale'
+
+    def __init__(self, net, idx, D, N, H, clip, ndir, use_peepholes, use_layer_norm, learn_init):
+        if learn_init:
+            raise NotImplementedError('asr_amd: EqualScaleHyperLSTMLayer with learn_init=True is not built (the learned '
+                                      'inner_hid_init row is in the projected space; see EqualScaleStepPair)')
+        if N % 4 or H % 4:
+            raise ValueError('asr_amd: EqualScaleHyperLSTMLayer needs both unit counts divisible by 4')
+        self.net = net; self.idx = idx
+        self.D, self.N, self.Href = D, N, H
+        self.H = N                                  # the kernels' inner width
+        self.peep, self.ln, self.learn_init = bool(use_peepholes), bool(use_layer_norm), False
+        self.NS = 4 if self.peep else 3
+        self.clip = float(clip); self.ndir = ndir
+        self.out_dim = ndir * N
+        self.dirs = [_mk_equal_scale(net.store, 'L%d.%d.' % (idx, d), D, N, H, self.peep, self.ln) for d in range(ndir)]
+        self.kdirs = [_FoldedDir(dp) for dp in self.dirs]
+        self.reverse = [False, True][:ndir]
+        self.inner_grad = [None] * ndir
+        self._ext = [None] * ndir
+
+    def describe(self):
+        out = ScalingStepPair.describe(self)
+        for d, nm in enumerate(('fwd', 'bwd')):
+            if out[nm] is not None:
+                out[nm]['kind'] = 'equalscale'
+                out[nm]['args']['num_inner_units'] = self.Href
+        return out
+
+    def inner_hid(self, d):
+        """(T*B, num_inner_units): the projected inner hidden sequence of the last forward."""
+        u = self.ctx['d'][d]['hid'][:, :self.H]
+        return ops.gemm(u, self.dirs[d].p('P'), self._buf('ihid%d' % d, u.shape[0], self.Href))
+
+    def forward(self, X, T, B, mask, cond, train):
+        U, Hr, N = self.H, self.Href, self.N
+        for d, (dp, k) in enumerate(zip(self.dirs, self.kdirs)):
+            Wio = self._buf('Wio_f%d' % d, U + N, 4 * U)
+            ops.gemm(dp.p('P'), dp.p('Whh'), Wio[:U])
+            Wio[U:].copy_(dp.p('Woi'))
+            k.fold['Wio'] = Wio
+            k.fold['S'] = ops.gemm(dp.p('P'), dp.p('S'), self._buf('S_f%d' % d, U, self.NS * 4 * N))
+            k.gfold['Wio'] = self._buf('gWio_f%d' % d, U + N, 4 * U)
+            k.gfold['S'] = self._buf('gS_f%d' % d, U, self.NS * 4 * N)
+        return ScalingStepPair.forward(self, X, T, B, mask, cond, train)
+
+    def backward(self, dY, need_dx=True):
+        rows = self.ctx['T'] * self.ctx['B']
+        for d, dp in enumerate(self.dirs):          # an outside consumer's gradient on the projected sequence -> on u
+            self._ext[d] = ext = self.inner_grad[d]
+            if ext is not None:
+                self.inner_grad[d] = ops.gemm(ext, dp.p('P'), self._buf('du_ext%d' % d, rows, self.H), tb=True)
+        return ScalingStepPair.backward(self, dY, need_dx)
+
+    def _param_grads(self, ctx, rows, T, B):
+        ScalingStepPair._param_grads(self, ctx, rows, T, B)
+        U = self.H
+        for d, (dp, k) in enumerate(zip(self.dirs, self.kdirs)):
+            gW, gS, P = k.gfold['Wio'], k.gfold['S'], dp.p('P')
+            ops.gemm(P, gW[:U], dp.g('Whh'), ta=True)
+            dp.g('Woi').copy_(gW[U:])
+            ops.gemm(P, gS, dp.g('S'), ta=True)
+            ops.gemm(gW[:U], dp.p('Whh'), dp.g('P'), tb=True)
+            ops.gemm(gS, dp.p('S'), dp.g('P'), tb=True, beta=1.0)
+            if self._ext[d] is not None:
+                ops.gemm(ctx['d'][d]['hid'][:, :U], self._ext[d], dp.g('P'), ta=True, beta=1.0)
+                self._ext[d] = None

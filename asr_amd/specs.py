@@ -236,6 +236,30 @@ def scaling_hyper_params(D, H, N, use_peepholes=False, use_layer_norm=False, lea
     return out
 
 
+def equal_scale_hyper_params(D, H, N, use_peepholes=False, use_layer_norm=False, learn_init=False):
+    """EqualScaleHyperLSTMLayer, libs/lasagne_libs/hyper_layers.py:1252-1521, trainable parameters in add_param order: the
+    ScalingHyperLSTMLayer with an inner cell as wide as the outer one (N gates columns per gate, :1258-1292) whose hidden
+    state is projected to the H inner units by W_inner_hid_prj (:1340-1342, applied at :1709) before it is carried, fed
+    back and mapped to the four scales.  Same trainable / non-trainable rules and naming as scaling_hyper_params."""
+    out = []
+    for g in GATES_REC:
+        fb = 1.0 if g == 'forgetgate' else 0.0
+        out += [('W_inner_in_to_inner_' + g, (D, N), 'orthogonal'), ('W_inner_hid_to_inner_' + g, (H, N), 'orthogonal')]
+        if use_peepholes and g != 'cell':
+            out += [('W_inner_cell_to_inner_' + g, (N,), ('uniform', 0.1))]
+        out += [('W_outer_hid_to_inner_' + g, (N, N), 'orthogonal'), ('b_inner_' + g, (N,), ('const', fb))]
+        if use_layer_norm:
+            out += [('W_inner_ln_' + g, (N,), ('const', 1.0)), ('b_inner_ln_' + g, (N,), ('const', 0.0))]
+    out += [('W_inner_hid_prj', (N, H), 'orthogonal')]
+    if use_layer_norm:
+        out += [('W_inner_ln_outcell', (N,), ('const', 1.0)), ('b_inner_ln_outcell', (N,), ('const', 0.0))]
+    if learn_init:
+        out += [('inner_cell_init', (1, N), ('const', 0.0)), ('inner_hid_init', (1, H), ('const', 0.0))]
+    inner = [r[0] for r in scaling_hyper_params(D, H, N, use_peepholes, use_layer_norm, learn_init)]
+    outer_from = inner.index('W_outer_in_to_outer_ingate')
+    return out + scaling_hyper_params(D, H, N, use_peepholes, use_layer_norm, learn_init)[outer_from:]
+
+
 def hyperlhuc_params(D, N, H, Z, reparam='relu'):
     """HyperLHUCLSTMLayer, libs/lasagne_libs/hyper_lhuc_layers.py:533-555 (init_weights, then
     init_main_lstm_weights :521-525).  Gate.b defaults to Constant(0.) (lasagne Gate)."""

@@ -482,6 +482,7 @@ def _scal_cell_bwd(dh, dc_in, c_prev, peep, lnp, cache, U, use_ln, clipv):
 def scaling_scan_fwd(x, mask, p, spec):
     T, B, D = x.shape
     N, H = spec['N'], spec['H']
+    U = spec.get('U', H)                                  # inner cell width: H, or N for EqualScaleHyperLSTMLayer (:1258-1292)
     use_ln, peep = spec.get('ln', False), spec.get('peep', False)
     dt = x.dtype
     inner_in = x @ p['Wi_x'] + p['bi']                    # :951
@@ -495,7 +496,8 @@ def scaling_scan_fwd(x, mask, p, spec):
     for t in order:
         m = mask[t][:, None] != 0
         ig = inner_in[t] + ih @ p['Wi_h'] + oh @ p['Wi_o']            # :973-975
-        ic_new, ih_new, cin = _scal_cell_fwd(ig, ic, p['wpeep'][None, :], (p['ln_ia'], p['ln_ib']), H, use_ln)
+        ic_new, u_new, cin = _scal_cell_fwd(ig, ic, p['wpeep'][None, :], (p['ln_ia'], p['ln_ib']), U, use_ln)
+        ih_new = u_new @ p['P'] if 'P' in p else u_new                # EqualScale: inner_hid . W_inner_hid_prj (:1709)
         s_in = ih_new @ p['S_in'] + p['s_in']                         # :1030
         s_hid = ih_new @ p['S_hid'] + p['s_hid']                      # :1031
         s_cl = ih_new @ p['S_cell'] + p['s_cell'] if peep else zeroN  # :1032
@@ -503,7 +505,7 @@ def scaling_scan_fwd(x, mask, p, spec):
         a = oh @ p['Wo_h']
         og = s_in * outer_in[t] + s_hid * a + s_b                     # :1038-1040
         oc_new, oh_new, cout = _scal_cell_fwd(og, oc, s_cl, (p['ln_oa'], p['ln_ob']), N, use_ln)
-        cache[t] = (m, ic, ih, oc, oh, ih_new, s_in, s_hid, s_cl, a, cin, cout)
+        cache[t] = (m, ic, ih, oc, oh, ih_new, s_in, s_hid, s_cl, a, cin, cout, u_new)
         ic = np.where(m, ic_new, ic); ih = np.where(m, ih_new, ih)    # step_masked :1097-1118
         oc = np.where(m, oc_new, oc); oh = np.where(m, oh_new, oh)
         hid_i[t] = ih; hid_o[t] = oh
@@ -514,16 +516,17 @@ def scaling_scan_bwd(dhid_i, dhid_o, x, fwd_cache, p, spec):
     cache, inner_in, outer_in = fwd_cache
     T, B, D = x.shape
     N, H = spec['N'], spec['H']
+    U = spec.get('U', H)
     use_ln, peep = spec.get('ln', False), spec.get('peep', False)
     clipv = spec.get('grad_clip', 0)
     dt = dhid_o.dtype
     order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
     g_ = {k: np.zeros_like(v) for k, v in p.items()}
     doh = np.zeros((B, N), dt); doc = np.zeros((B, N), dt)
-    dih = np.zeros((B, H), dt); dic = np.zeros((B, H), dt)
-    d_inner_in = np.zeros((T, B, 4 * H), dt); d_outer_in = np.zeros((T, B, 4 * N), dt)
+    dih = np.zeros((B, H), dt); dic = np.zeros((B, U), dt)
+    d_inner_in = np.zeros((T, B, 4 * U), dt); d_outer_in = np.zeros((T, B, 4 * N), dt)
     for t in reversed(order):
-        (m, ic_prev, ih_prev, oc_prev, oh_prev, ih_new, s_in, s_hid, s_cl, a, cin, cout) = cache[t]
+        (m, ic_prev, ih_prev, oc_prev, oh_prev, ih_new, s_in, s_hid, s_cl, a, cin, cout, u_new) = cache[t]
         doh_t = dhid_o[t] + doh
         dih_t = dhid_i[t] + dih
         doh_new = np.where(m, doh_t, 0); doh_prev = np.where(m, 0, doh_t)
@@ -546,8 +549,12 @@ def scaling_scan_bwd(dhid_i, dhid_o, x, fwd_cache, p, spec):
             g_['s_' + nm] += dsv.sum(0)
             dih_new = dih_new + dsv @ p['S_' + nm].T
         # inner cell (:977-1025)
-        dig, dcp, dwp, (dal, dbe) = _scal_cell_bwd(dih_new, dic_new, ic_prev, p['wpeep'][None, :], (p['ln_ia'], p['ln_ib']),
-                                                   cin, H, use_ln, clipv)
+        du = dih_new
+        if 'P' in p:
+            g_['P'] += u_new.T @ dih_new
+            du = dih_new @ p['P'].T
+        dig, dcp, dwp, (dal, dbe) = _scal_cell_bwd(du, dic_new, ic_prev, p['wpeep'][None, :], (p['ln_ia'], p['ln_ib']),
+                                                   cin, U, use_ln, clipv)
         dic_prev = dic_prev + dcp
         g_['wpeep'] += dwp.sum(0)
         g_['ln_ia'] += dal.sum(1); g_['ln_ib'] += dbe.sum(1)
@@ -1139,8 +1146,9 @@ class ScalingHyperLSTMLayerO(OracleLayer):
     def forward(self, x, mask, cond=None):
         P = self.P; G = GATES_REC; sp = self.spec
         N, H = sp['N'], sp['H']
+        U = sp.get('U', H)
         dt = np.asarray(x).dtype
-        zH = np.zeros(H, dt); zHN = np.zeros((H, N), dt); zN = np.zeros(N, dt)
+        zH = np.zeros(U, dt); zHN = np.zeros((H, N), dt); zN = np.zeros(N, dt)
         pk = lambda fmt, z: np.concatenate([P[fmt.format(g)] if (sp['peep'] and g != 'cell') else z for g in G], axis=-1)
         lnv = lambda pre, wb, U: np.stack([P['%s_%s_ln_%s' % (wb, pre, g)] if sp['ln'] else np.zeros(U, dt) for g in self.LN5])
         ini = lambda nm, U: P[nm] if sp['learn_init'] else np.zeros((1, U), dt)
@@ -1153,9 +1161,11 @@ class ScalingHyperLSTMLayerO(OracleLayer):
                       s_bias=_stack(P, 'b_inner_hid_to_outer_bias_{}', G, 0),
                       wpeep=pk('W_inner_cell_to_inner_{}', zH), S_cell=pk('W_inner_hid_to_outer_cell_{}', zHN),
                       s_cell=pk('b_inner_hid_to_outer_cell_{}', zN),
-                      ln_ia=lnv('inner', 'W', H), ln_ib=lnv('inner', 'b', H), ln_oa=lnv('outer', 'W', N), ln_ob=lnv('outer', 'b', N),
-                      ic0=ini('inner_cell_init', H), ih0=ini('inner_hid_init', H), oc0=ini('outer_cell_init', N),
+                      ln_ia=lnv('inner', 'W', U), ln_ib=lnv('inner', 'b', U), ln_oa=lnv('outer', 'W', N), ln_ob=lnv('outer', 'b', N),
+                      ic0=ini('inner_cell_init', U), ih0=ini('inner_hid_init', H), oc0=ini('outer_cell_init', N),
                       oh0=ini('outer_hid_init', N))
+        if 'U' in sp:
+            self.p['P'] = P['W_inner_hid_prj']
         self.x = _tm(x); m = _tm(mask[:, :, None])[:, :, 0]
         hid_i, hid_o, self.cache = scaling_scan_fwd(self.x, m, self.p, self.spec)
         self.inner_hid = _tm(hid_i)
@@ -1186,8 +1196,23 @@ class ScalingHyperLSTMLayerO(OracleLayer):
                     G['W_%s_ln_%s' % (pre, gname)] = g[ka][k]; G['b_%s_ln_%s' % (pre, gname)] = g[kb][k]
         if sp['learn_init']:
             G.update(inner_cell_init=g['ic0'], inner_hid_init=g['ih0'], outer_cell_init=g['oc0'], outer_hid_init=g['oh0'])
+        if 'P' in g:
+            G['W_inner_hid_prj'] = g['P']
         self.grads = G
         return _tm(dx)
+
+
+class EqualScaleHyperLSTMLayerO(ScalingHyperLSTMLayerO):
+    """libs/lasagne_libs/hyper_layers.py:1207-1890: ScalingHyperLSTMLayer's step (:1646-1779 is :963-1095 again) with an
+    inner cell of num_outer_units columns per gate (slice_outer on the inner gates, :1660-1689) and
+    inner_hid = (sigmoid(outgate) * tanh(outcell)) . W_inner_hid_prj (:1708-1709), num_inner_units wide, as the state that
+    is carried, fed back (:1657) and mapped to the scales (:1714-1717)."""
+
+    def __init__(self, P, num_inner_units, num_outer_units, grad_clipping=0, backwards=False, use_peepholes=False,
+                 use_layer_norm=False, learn_init=False):
+        ScalingHyperLSTMLayerO.__init__(self, P, num_inner_units, num_outer_units, grad_clipping, backwards, use_peepholes,
+                                        use_layer_norm, learn_init)
+        self.spec['U'] = num_outer_units
 
 
 # --------------------------------------------------------------------------------------------
@@ -1316,7 +1341,7 @@ def gen_win(batch, win_size, right_context=0):
 # --------------------------------------------------------------------------------------------
 _KINDS = dict(lstm=LSTMLayerO, lhuc=LHUCLSTMLayerO, prj=ProjectLSTMLayerO,
               ln_prj=LayerNormProjectLSTMLayerO, icond_ln_prj=InputCondLayerNormProjectLSTMLayerO,
-              hyper=HyperLSTMLayerO, rec=RecLayerO, scaling=ScalingHyperLSTMLayerO,
+              hyper=HyperLSTMLayerO, rec=RecLayerO, scaling=ScalingHyperLSTMLayerO, equalscale=EqualScaleHyperLSTMLayerO,
               hyperlhuc=HyperLHUCLSTMLayerO, prjhyper=ProjectionHyperLSTMLayerO)
 
 

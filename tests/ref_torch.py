@@ -322,10 +322,15 @@ def seqsum_lhuc_net(ss, layers, x, mask, N, npl, clip=0):
 
 
 def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False, use_peepholes=False, use_layer_norm=False,
-                        learn_init=False, return_inner=False):
+                        learn_init=False, return_inner=False, equal_scale=False):
     """libs/lasagne_libs/hyper_layers.py:850-1205, line by line.  Without use_peepholes the peephole vectors and the
     scale_outer_cell map are zero constants (:585,:716-723); the cell gate's peephole is a zero constant always
-    (cell_trainable=False, :642-644,:791-793).  Returns outer hid (or [inner hid, outer hid])."""
+    (cell_trainable=False, :642-644,:791-793).  Returns outer hid (or [inner hid, outer hid]).
+    equal_scale=True: EqualScaleHyperLSTMLayer (:1537-1890), the same step with an inner cell of N columns per gate
+    (slice_outer, :1660-1689) and inner_hid projected by W_inner_hid_prj (:1709)."""
+    HR = H                                  # width of the carried inner hidden state
+    if equal_scale:
+        H = N                               # width of the inner cell
     c = lambda fmt, dim=1: _cat(P, fmt, G_R, dim)
     W_ii = c('W_inner_in_to_inner_{}'); W_hi = c('W_inner_hid_to_inner_{}'); W_oi = c('W_outer_hid_to_inner_{}')
     b_i = c('b_inner_{}', 0)
@@ -333,7 +338,7 @@ def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False, use_peepholes
     W_hd = c('W_inner_hid_to_outer_hid_{}'); b_hd = c('b_inner_hid_to_outer_hid_{}', 0)
     W_bs = c('W_inner_hid_to_outer_bias_{}'); b_bs = c('b_inner_hid_to_outer_bias_{}', 0)
     W_oo_in = c('W_outer_in_to_outer_{}'); W_oo = c('W_outer_hid_to_outer_{}')
-    zH = torch.zeros(H, dtype=x.dtype); zHN = torch.zeros(H, N, dtype=x.dtype); zN = torch.zeros(N, dtype=x.dtype)
+    zH = torch.zeros(H, dtype=x.dtype); zHN = torch.zeros(HR, N, dtype=x.dtype); zN = torch.zeros(N, dtype=x.dtype)
     pk = lambda g: P['W_inner_cell_to_inner_' + g] if (use_peepholes and g != 'cell') else zH
     W_cl = torch.cat([P['W_inner_hid_to_outer_cell_' + g] if (use_peepholes and g != 'cell') else zHN for g in G_R], 1)
     b_cl = torch.cat([P['b_inner_hid_to_outer_cell_' + g] if (use_peepholes and g != 'cell') else zN for g in G_R], 0)
@@ -362,6 +367,8 @@ def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False, use_peepholes
         i_o = grad_clip(lnorm(i_o, 'inner', 'outgate'), clip)
         inner_outcell = grad_clip(lnorm(inner_cell, 'inner', 'outcell'), clip)                 # :1007-1022
         inner_hid = torch.sigmoid(i_o) * torch.tanh(inner_outcell)                             # :1025
+        if equal_scale:
+            inner_hid = inner_hid @ P['W_inner_hid_prj']                                       # :1709
         s_in = inner_hid @ W_in + b_in; s_hid = inner_hid @ W_hd + b_hd                        # :1030-1033
         s_cl = inner_hid @ W_cl + b_cl; s_b = inner_hid @ W_bs + b_bs
         og = s_in * outer_input_n + s_hid * (oh_prev @ W_oo) + s_b                             # :1038-1040
@@ -381,7 +388,7 @@ def scaling_hyper_layer(P, x, mask, N, H, clip=0, backwards=False, use_peepholes
     ones = torch.ones(B, 1, dtype=x.dtype)
     init = lambda nm, n: ones @ P[nm] if learn_init else torch.zeros(B, n, dtype=x.dtype)     # :1127-1131
     outs = _scan(step, [inner_input, outer_input, m],
-                 [init('inner_cell_init', H), init('inner_hid_init', H), init('outer_cell_init', N), init('outer_hid_init', N)],
+                 [init('inner_cell_init', H), init('inner_hid_init', HR), init('outer_cell_init', N), init('outer_hid_init', N)],
                  backwards)
     hid = outs[3].transpose(0, 1)
     hid = hid.flip(1) if backwards else hid

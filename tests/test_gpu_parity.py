@@ -309,6 +309,42 @@ def test_scaling_hyper_options_small(peep, ln, li, clip):
     run_case(net, b)
 
 
+@pytest.mark.parametrize('peep,ln', [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize('clip', [0.0, 0.05])
+def test_equal_scale_hyper_small(peep, ln, clip):
+    """EqualScaleHyperLSTMLayer (hyper_layers.py:1207-1890): the scaling layer's step with an inner cell as wide as the outer
+    one and its hidden state projected to the inner units; two stacked bidirectional layers, ragged lengths.  The kernels
+    run the projection folded into its consumers (engine_scaling.EqualScaleStepPair), the oracle runs it as written."""
+    from asr_amd.gating_hyper_nets import deep_equal_scale_hyper_model
+    net = deep_equal_scale_hyper_model(None, None, 5, 6, [4, 8], [12, 8], use_peepholes=peep, use_layer_norm=ln,
+                                       grad_clipping=clip, device=_dev(), seed=71)
+    perturb_params(net, 72, 0.15)
+    b = make_batch(np.random.default_rng(73), 3, 7, 5, 6)
+    run_case(net, b)
+
+
+def test_equal_scale_hyper_medium_inner_hid_and_limits():
+    """64 outer / 16 inner units, 18 rows (two batch chunks), T = 29, every option; the projected inner hidden sequences of
+    get_inner_hid=True against the oracle's; learn_init is refused."""
+    from asr_amd.gating_hyper_nets import deep_equal_scale_hyper_model
+    out = deep_equal_scale_hyper_model(None, None, 11, 13, [16], [64], use_peepholes=True, use_layer_norm=True,
+                                       grad_clipping=1.0, get_inner_hid=True, device=_dev(), seed=74)
+    net = out[-1]; inner = out[:-1]
+    perturb_params(net, 75, 0.05)
+    b = make_batch(np.random.default_rng(76), 18, 29, 11, 13)
+    run_case(net, b, calibrate=True)
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    onet.posteriors(b['x'], b['mask'], None)
+    x = torch.from_numpy(b['x']).to(net.device); m = torch.from_numpy(b['mask']).to(net.device)
+    net.posteriors(x, m, None)
+    for k, h in enumerate(inner):
+        got = h.get_output().cpu().numpy().reshape(29, 18, -1).transpose(1, 0, 2)
+        assert got.shape[-1] == 16
+        assert relerr(got, onet.layers[0][k].inner_hid) < 2e-5, k
+    with pytest.raises(NotImplementedError):
+        deep_equal_scale_hyper_model(None, None, 5, 6, [4], [8], learn_init=True, device=_dev())
+
+
 def test_step_loop_layers_more_rows_than_one_call():
     """B = 67: the step-loop layers take 64 rows per C-ABI call (four 16-row chunks in every launch), the caller loops
     over calls: one call of 64 rows and one of 3."""

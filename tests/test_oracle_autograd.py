@@ -132,6 +132,19 @@ def test_scaling_hyper_layer_options(backwards, peep, ln, li):
 
 
 @pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('peep,ln,li', [(False, False, False), (True, False, False), (False, True, False), (True, True, True)])
+def test_equal_scale_hyper_layer(backwards, peep, ln, li):
+    """EqualScaleHyperLSTMLayer (hyper_layers.py:1207-1890): inner cell N wide, hidden state projected to the inner units."""
+    rng = np.random.default_rng(31)
+    Hs = 6
+    P = make_params(rng, specs.equal_scale_hyper_params(D, Hs, N, peep, ln, li), perturb=0.3, scale=1.5)
+    b = make_batch(rng, B, T, D, C)
+    lay = O.EqualScaleHyperLSTMLayerO(P, Hs, N, 0.3, backwards, peep, ln, li)
+    _check(lay, lambda Pt, x, m, c: R.scaling_hyper_layer(Pt, x, m, N, Hs, 0.3, backwards, peep, ln, li, equal_scale=True),
+           P, b['x'], b['mask'])
+
+
+@pytest.mark.parametrize('backwards', [False, True])
 @pytest.mark.parametrize('clip,reparam', [(0, 'relu'), (0.3, 'relu'), (0.3, 'exp'), (0, '2sigmoid'), (0, 'identity')])
 def test_hyperlhuc_layer(backwards, clip, reparam):
     rng = np.random.default_rng(23)

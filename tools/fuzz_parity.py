@@ -27,7 +27,7 @@ def pick(rng, xs):
 
 def make_case(rng):
     fam = pick(rng, ['lstm', 'lstm', 'ln_prj', 'ivec_cond', 'hyper', 'hyper', 'hyperlhuc', 'scaling', 'scaling_opt', 'prjhyper',
-                     'lhuc_ivec', 'rec'])
+                     'lhuc_ivec', 'rec', 'equalscale'])
     D = int(rng.integers(1, 24)); C = int(rng.integers(2, 40))
     B = int(pick(rng, [1, 2, 3, 5, 15, 16, 17, 18, 31, 33, 40])); T = int(pick(rng, [1, 2, 3, 7, 19, 33, 64]))
     lengths = [int(rng.integers(1, T + 1)) for _ in range(B)]
@@ -69,6 +69,12 @@ def make_case(rng):
                 opt['use_layer_norm'] = True
         p.update(Hs=Hs, Ns=Ns, opt=opt)
         mk = lambda: G.deep_scaling_hyper_model(None, None, D, C, Hs, Ns, grad_clipping=clip, device=DEV, seed=1, **opt)
+    elif fam == 'equalscale':
+        Hs = [int(pick(rng, [4, 8, 16])) for _ in range(L)]
+        Ns = [max(min(N, 64) // 4 * 4, h) for h in Hs]
+        opt = dict(use_peepholes=bool(rng.integers(2)), use_layer_norm=bool(rng.integers(2)))
+        p.update(Hs=Hs, Ns=Ns, opt=opt)
+        mk = lambda: G.deep_equal_scale_hyper_model(None, None, D, C, Hs, Ns, grad_clipping=clip, device=DEV, seed=1, **opt)
     elif fam == 'prjhyper':
         N = min(N, 64); F = int(pick(rng, [4, 8, 12])); F = min(F, N); p.update(N=N, F=F)
         mk = lambda: G.deep_projection_hyper_model(None, None, D, C, L, F, N, grad_clipping=clip, device=DEV, seed=1)[0]
