@@ -363,7 +363,7 @@ def main():
         steps_per_launch = float(np.mean([rows / BATCH for rows, _, _ in bwd]))
         ach = byts / (ms * 1e-3) / 1e9
         traffic = None       # HBM/fabric bytes per launch of the same kernel from the committed PMC passes
-        pj = os.path.join(ROOT, 'profiles', 'r02c_pmc_hyper_scan_bwd.json')
+        pj = os.path.join(ROOT, 'profiles', 'r02g_pmc_hyper_scan_bwd.json')
         if os.path.exists(pj):
             with open(pj) as f:
                 pm = json.load(f)
