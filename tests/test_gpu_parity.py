@@ -651,3 +651,15 @@ def test_work_issued_ahead_on_the_side_stream_changes_no_bit(kind):
     for (ce1, g1), (ce0, g0) in zip(a, c):
         assert ce1 == ce0
         assert torch.equal(g1, g0)
+
+
+def test_shape_fuzz_fixed_seed():
+    """60 cases of tools/fuzz_parity.py (random layer family, widths, batch, ragged lengths, clip, direction) against the
+    oracle: none may fail; refusals must name a limit (the fuzzer counts only those as refused).  The tool's header says
+    what a 'noisy' case is; DESIGN.md section 8 has the 3550-case record."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_parity
+    ok, noisy, refused, failed = fuzz_parity.run(60, 5)
+    assert failed == 0
+    assert ok >= 45
