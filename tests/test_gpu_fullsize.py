@@ -121,30 +121,6 @@ def test_full_size_row_independence_and_padding(cfg):
     assert relerr(sub * valid, full[rows, :Ts] * valid) < 2e-6
 
 
-@pytest.mark.parametrize('cfg,reps', [(2, 25), (4, 25), (3, 12)])
-def test_full_size_training_step_reproduces_bit_for_bit(cfg, reps):
-    """The same full-size batch through loss + backward `reps` times: loss and every gradient bit equal to the first
-    repetition's.  The scans hand data between workgroups inside a launch while parameter-gradient GEMMs run beside them
-    on the side stream; a stale hand-off read, or a value the compiler moved across a hand-off, shows here as a differing
-    bit (it did once: DESIGN.md section 8; before that fix about two of three cfg2 repetitions differed).
-    tools/soak_determinism.py is the longer form."""
-    net, cond_key = build_cfg(cfg, seed=1)
-    b = _batch(cfg)
-    x, m, y = _t(b['x']), _t(b['mask']), _t(b['y'])
-    cond = _t(b[cond_key]) if cond_key else None
-    first = None
-    differ = 0
-    for _ in range(reps):
-        ce, _, _ = net.loss(x, m, y, m, cond)
-        net.backward()
-        if first is None:
-            first = (ce.clone(), net.store.g.clone())
-        elif not (torch.equal(ce, first[0]) and torch.equal(net.store.g, first[1])):
-            differ += 1
-    net.check_status()
-    assert differ == 0, '%d of %d repetitions differ from the first' % (differ, reps - 1)
-
-
 def test_cfg3_full_size_data_parallel_linearity():
     """One process plays two ranks: each half of the global batch (B=16 -> 2 x 8 rows, sharded by length
     as asr_amd.dp.shard_batch does) is run with world=2; the summed gradients equal the
