@@ -896,16 +896,27 @@ class Network(object):
         self._last_groups = getattr(self, '_last_groups', {})
         self._last_groups[('lstm', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
 
-    def scan_hyper(self, pair, desc, backward):
+    def scan_hyper(self, pair, desc, backward, key=None):
         L = _lib.lib()
+        if desc.ndir == 2 and 128 < desc.N // 4 <= 256:
+            # one workgroup per 4 units and 256 co-resident workgroups: above 512 units the two directions of a
+            # bidirectional layer do not fit one launch; they are independent, so each gets a launch of its own
+            for d in range(2):
+                one = type(desc)()
+                C.memmove(C.byref(one), C.byref(desc), C.sizeof(desc))
+                one.ndir = 1
+                one.dir[0] = desc.dir[d]
+                self.scan_hyper(pair, one, backward, key=('hyper', pair.idx, backward, d))
+            return
+        key = key or ('hyper', pair.idx, backward)
         need = L.asr_hyper_scan_ws_bytes(desc.T, desc.B, desc.N, desc.H, desc.ndir, int(backward))
-        ws = self._workspace(('hyper', pair.idx, backward), need)
+        ws = self._workspace(key, need)
         fn = L.asr_hyper_scan_bwd if backward else L.asr_hyper_scan_fwd
         check(self._timed('hyper', backward, desc, lambda: fn(C.byref(desc), ws.data_ptr(), ws.numel(),
                                                               torch.cuda.current_stream().cuda_stream)),
               'asr_hyper_scan_%s' % ('bwd' if backward else 'fwd'))
         self._last_groups = getattr(self, '_last_groups', {})
-        self._last_groups[('hyper', pair.idx, backward)] = desc.ndir * ((desc.B + 7) // 8)
+        self._last_groups[key] = desc.ndir * ((desc.B + 7) // 8)
 
     def check_status(self):
         """Call after a host sync: raises if any persistent scan gave up on a bounded wait."""

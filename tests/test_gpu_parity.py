@@ -250,6 +250,20 @@ def test_hyperlstm_medium():
     run_case(net, b)
 
 
+def test_hyperlstm_wider_than_one_launch_holds():
+    """N = 1024 bidirectional: 2 x 256 workgroups do not fit one persistent launch, the directions run as one launch each
+    (Network.scan_hyper).  B = 18 (two batch chunks), ragged lengths; and the scaling layer on the same scan."""
+    from asr_amd.builders import build_deep_hyperlstm
+    from asr_amd.gating_hyper_nets import deep_scaling_hyper_model
+    net = build_deep_hyperlstm('hyper', None, None, 11, 2, 1024, 32, 8, 13, 1.0, True, 0, device=_dev(), seed=81)
+    perturb_params(net, 82, 0.01)
+    b = make_batch(np.random.default_rng(83), 18, 9, 11, 13)
+    run_case(net, b)
+    net = deep_scaling_hyper_model(None, None, 11, 13, [16], [1024], grad_clipping=1.0, device=_dev(), seed=84)
+    perturb_params(net, 85, 0.01)
+    run_case(net, b)
+
+
 @pytest.mark.parametrize('clip', [0.0, 0.05])
 @pytest.mark.parametrize('H', [4, 6])
 def test_scaling_hyper_small(clip, H):

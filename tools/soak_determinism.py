@@ -32,6 +32,19 @@ cases = [
                                                                    device=dev, seed=1), max(reps // 4, 4)),
     ('ScalingHyper scan 250/500', 1, lambda: G.deep_scaling_hyper_model(None, None, 123, 61, [250, 250], [500, 500],
                                                                         grad_clipping=1.0, device=dev, seed=1), reps),
+    # kernel variants the five configurations do not reach: per-gate LN (2-D backward, PG = 1), LN at a width the 2-D
+    # backward does not take (N = 320: lstm_scan_bwd_kernel's LN path), a net wider than the register chunk (N = 1024)
+    ('per-gate LN 2x512 (v0_2)', 2, lambda: G._build_rec(123, 3436, 2, 512, 1.0, 0.0, 'LayerNormProjectLSTM_v0_2_Layer', None, 0,
+                                                         num_factors=None, num_prjs=256, device=dev, seed=1)[0], reps),
+    ('cond per-gate LN 2x512', 2, lambda: G._build_rec(123, 3436, 2, 512, 1.0, 0.0, 'LayerNormProjectLSTM_v0_1_Layer',
+                                                       'CondLayerNormProjectLSTM_v0_2_Layer', 2, num_factors=64,
+                                                       num_prjs=256, device=dev, seed=1)[0], reps),
+    ('LN-LSTM 2x320', 1, lambda: builders.build_deep_lstm(None, None, 123, 2, 320, 0, 61, 1.0, True, True, 0, device=dev,
+                                                          seed=1), reps),
+    ('LSTMP 2x1024', 1, lambda: builders.build_deep_lstm(None, None, 123, 2, 1024, 256, 61, 1.0, True, False, 0, device=dev,
+                                                         seed=1), reps),
+    ('HyperLSTM 2x1024', 1, lambda: builders.build_deep_hyperlstm('hyper', None, None, 123, 2, 1024, 128, 64, 61, 1.0, True, 0,
+                                                                  device=dev, seed=1), max(reps // 2, 4)),
 ]
 bad = 0
 for name, cfg, mk, n in cases:
