@@ -885,16 +885,32 @@ class Network(object):
         self.scan_events.append((kind, bool(backward), steps * desc.B, desc.ndir, e0, e1))
         return r
 
-    def scan_lstm(self, pair, desc, backward):
+    def scan_lstm(self, pair, desc, backward, key=None):
         L = _lib.lib()
+        what = 'asr_lstm_scan_%s' % ('bwd' if backward else 'fwd')
+        key = key or ('lstm', pair.idx, backward)
         need = L.asr_lstm_scan_ws_bytes(desc.T, desc.B, desc.N, desc.ndir, int(backward))
-        ws = self._workspace(('lstm', pair.idx, backward), need)
+        ws = self._workspace(key, need)
         fn = L.asr_lstm_scan_bwd if backward else L.asr_lstm_scan_fwd
-        check(self._timed('lstm', backward, desc, lambda: fn(C.byref(desc), ws.data_ptr(), ws.numel(),
-                                                             torch.cuda.current_stream().cuda_stream)),
-              'asr_lstm_scan_%s' % ('bwd' if backward else 'fwd'))
+        rc = self._timed('lstm', backward, desc, lambda: fn(C.byref(desc), ws.data_ptr(), ws.numel(),
+                                                            torch.cuda.current_stream().cuda_stream))
+        if rc == -1 and desc.ndir == 2:
+            # the library refuses a grid or an LDS share that cannot be co-resident before it launches anything; the two
+            # directions of a layer are independent, so a layer too wide for one launch gets one launch per direction
+            for d in range(2):
+                one = type(desc)()
+                C.memmove(C.byref(one), C.byref(desc), C.sizeof(desc))
+                one.ndir = 1
+                one.dir[0] = desc.dir[d]
+                self.scan_lstm(pair, one, backward, key=('lstm', pair.idx, backward, d))
+            return
+        if rc == -1:
+            raise _lib.AsrError('%s failed: ASR_ERR_ARG (-1); if the arguments are in order, %d units are more than the '
+                                'resident-weight scan holds (16*UT*N*4 bytes of LDS per workgroup, UT in {1,2,4}, at most '
+                                '256 workgroups of N/(4*UT) per direction: about 1024 units)' % (what, desc.N))
+        check(rc, what)
         self._last_groups = getattr(self, '_last_groups', {})
-        self._last_groups[('lstm', pair.idx, backward)] = desc.ndir * ((desc.B + 15) // 16)
+        self._last_groups[key] = desc.ndir * ((desc.B + 15) // 16)
 
     def scan_hyper(self, pair, desc, backward, key=None):
         L = _lib.lib()
@@ -909,6 +925,9 @@ class Network(object):
                 self.scan_hyper(pair, one, backward, key=('hyper', pair.idx, backward, d))
             return
         key = key or ('hyper', pair.idx, backward)
+        if desc.N // 4 > 256:
+            raise _lib.AsrError('asr_hyper_scan: %d units are more than the resident-weight scan holds (one workgroup per 4 '
+                                'units, at most 256 co-resident workgroups per direction: 1024 units)' % desc.N)
         need = L.asr_hyper_scan_ws_bytes(desc.T, desc.B, desc.N, desc.H, desc.ndir, int(backward))
         ws = self._workspace(key, need)
         fn = L.asr_hyper_scan_bwd if backward else L.asr_hyper_scan_fwd

@@ -250,6 +250,22 @@ def test_hyperlstm_medium():
     run_case(net, b)
 
 
+def test_lstm_width_that_needs_one_launch_per_direction_and_the_width_limit():
+    """516 units bidirectional: 129 workgroups per direction, 258 do not fit one launch and 516 is not a multiple of 8 (no
+    two-tile workgroups): Network.scan_lstm runs the directions one after the other.  2048 units: the weights alone are
+    more than the chip's LDS; the error says so."""
+    from asr_amd.builders import build_deep_lstm
+    from asr_amd._lib import AsrError
+    net = build_deep_lstm(None, None, 7, 2, 516, 0, 9, 1.0, True, True, 0, device=_dev(), seed=91)
+    perturb_params(net, 92, 0.01)
+    b = make_batch(np.random.default_rng(93), 3, 6, 7, 9)
+    run_case(net, b, calibrate=True)
+    net = build_deep_lstm(None, None, 7, 1, 2048, 0, 9, 1.0, True, False, 0, device=_dev(), seed=94)
+    x = torch.from_numpy(b['x']).to(net.device); m = torch.from_numpy(b['mask']).to(net.device)
+    with pytest.raises(AsrError, match='resident-weight scan holds'):
+        net.posteriors(x, m, None)
+
+
 def test_hyperlstm_wider_than_one_launch_holds():
     """N = 1024 bidirectional: 2 x 256 workgroups do not fit one persistent launch, the directions run as one launch each
     (Network.scan_hyper).  B = 18 (two batch chunks), ragged lengths; and the scaling layer on the same scan."""

@@ -19,6 +19,8 @@ from common import make_batch                                       # noqa: E402
 from test_gpu_parity import perturb_params, run_case                # noqa: E402
 
 DEV = 'cuda:0'
+CAP = 1024 if int(os.environ.get('FUZZ_WIDE', '0')) else 64   # width cap of the step-loop and rec families
+WIDE = bool(int(os.environ.get('FUZZ_WIDE', '0')))      # widths 320 .. 2048 (with B*T kept small by the rule below)
 
 
 def pick(rng, xs):
@@ -35,9 +37,12 @@ def make_case(rng):
     clip = float(pick(rng, [0.0, 0.05, 1.0]))
     bidir = bool(rng.integers(2))
     L = int(rng.integers(1, 4))
-    N = int(pick(rng, [4, 8, 12, 20, 36, 64, 100, 128, 132, 192, 256]))
+    N = int(pick(rng, [4, 8, 12, 20, 36, 64, 100, 128, 132, 192, 256] if not WIDE else [320, 512, 516, 768, 1024, 1536, 2048]))
     if B * T * N > 40 * 33 * 132:                       # keep the numpy oracle in seconds
-        N = min(N, 64)
+        if WIDE:
+            B, T = min(B, 5), min(T, 7); lengths = [min(l, T) for l in lengths[:B]]; lengths[0] = T
+        else:
+            N = min(N, 64)
     I = 0
     p = dict(fam=fam, D=D, C=C, B=B, T=T, clip=clip, bidir=bidir, L=L, N=N, lengths=lengths)
     if fam == 'lstm':
@@ -61,7 +66,7 @@ def make_case(rng):
         mk = lambda: f(fam, None, None, D, L, N, H, Z, C, clip, bidir, 0, device=DEV, seed=1)
     elif fam in ('scaling', 'scaling_opt'):
         Hs = [int(pick(rng, [2, 4, 6, 10, 16])) for _ in range(L)]
-        Ns = [max(N if fam == 'scaling' else min(N, 64), h) for h in Hs]
+        Ns = [max(N if fam == 'scaling' else min(N, CAP), h) for h in Hs]
         opt = {}
         if fam == 'scaling_opt':
             opt = dict(use_peepholes=bool(rng.integers(2)), use_layer_norm=bool(rng.integers(2)), learn_init=bool(rng.integers(2)))
@@ -71,12 +76,12 @@ def make_case(rng):
         mk = lambda: G.deep_scaling_hyper_model(None, None, D, C, Hs, Ns, grad_clipping=clip, device=DEV, seed=1, **opt)
     elif fam == 'equalscale':
         Hs = [int(pick(rng, [4, 8, 16])) for _ in range(L)]
-        Ns = [max(min(N, 64) // 4 * 4, h) for h in Hs]
+        Ns = [max(min(N, CAP) // 4 * 4, h) for h in Hs]
         opt = dict(use_peepholes=bool(rng.integers(2)), use_layer_norm=bool(rng.integers(2)))
         p.update(Hs=Hs, Ns=Ns, opt=opt)
         mk = lambda: G.deep_equal_scale_hyper_model(None, None, D, C, Hs, Ns, grad_clipping=clip, device=DEV, seed=1, **opt)
     elif fam == 'prjhyper':
-        N = min(N, 64); F = int(pick(rng, [4, 8, 12])); F = min(F, N); p.update(N=N, F=F)
+        N = min(N, CAP); F = int(pick(rng, [4, 8, 12])); F = min(F, N); p.update(N=N, F=F)
         mk = lambda: G.deep_projection_hyper_model(None, None, D, C, L, F, N, grad_clipping=clip, device=DEV, seed=1)[0]
     elif fam == 'lhuc_ivec':
         I = 3
@@ -85,7 +90,7 @@ def make_case(rng):
     else:
         cls = pick(rng, sorted(specs.REC_CLASSES)); v = specs.REC_CLASSES[cls]
         I = 3 if v['cond'] == 'ext' else 0
-        N = min(N, 64)
+        N = min(N, CAP)
         if N % 2:
             N += 1
         p.update(cls=cls, N=N)
@@ -151,7 +156,7 @@ def run(n, seed, only=None):
             print('[%3d] ok      %-s  post %.1e grad %.1e' % (k, tag, e, w), flush=True)
         except Exception as ex:                                    # noqa: BLE001
             msg = '%s: %s' % (type(ex).__name__, ex)
-            if ('limit' in msg.lower() or 'ASR_ERR_LIMIT' in msg or isinstance(ex, NotImplementedError)
+            if ('limit' in msg.lower() or 'ASR_ERR_LIMIT' in msg or 'resident-weight scan holds' in msg or isinstance(ex, NotImplementedError)
                     or (isinstance(ex, ValueError) and 'needs' in msg)):
                 refused += 1
                 print('[%3d] refused %-s  %s' % (k, tag, msg[:160]), flush=True)
