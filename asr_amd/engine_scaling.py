@@ -482,7 +482,7 @@ class EqualScaleStepPair(ScalingStepPair):
     folds into its consumers:  h_in.W_inner_hid_to_inner = u.(P.W_hh)  (:1657),  h_in.[scale maps] = u.(P.S)  (:1714-1717).
     The kernels therefore run a ScalingHyperLSTMLayer of inner width U with the folded weights; the inner hidden sequence
     is one GEMM after the loop, and the factors' gradients come from the folded ones by the product rule:
-      dW_hh = P^T.dA,  dS = P^T.dS',  dP = dA.W_hh^T + dS'.S^T (+ u^T.d h_in of an outside consumer).
+      dW_hh = P^T.dA,  dS = P^T.dS',  dP = dA.W_hh^T + dS'.S^T.
     learn_init is not built: inner_hid_init lives in the projected space and has no pre-image under the fold."""
     kind = 'equalscale'
 
@@ -503,7 +503,6 @@ class EqualScaleStepPair(ScalingStepPair):
         self.kdirs = [_FoldedDir(dp) for dp in self.dirs]
         self.reverse = [False, True][:ndir]
         self.inner_grad = [None] * ndir
-        self._ext = [None] * ndir
 
     def describe(self):
         out = ScalingStepPair.describe(self)
@@ -531,11 +530,8 @@ class EqualScaleStepPair(ScalingStepPair):
         return ScalingStepPair.forward(self, X, T, B, mask, cond, train)
 
     def backward(self, dY, need_dx=True):
-        rows = self.ctx['T'] * self.ctx['B']
-        for d, dp in enumerate(self.dirs):          # an outside consumer's gradient on the projected sequence -> on u
-            self._ext[d] = ext = self.inner_grad[d]
-            if ext is not None:
-                self.inner_grad[d] = ops.gemm(ext, dp.p('P'), self._buf('du_ext%d' % d, rows, self.H), tb=True)
+        if any(g is not None for g in self.inner_grad):     # no caller differentiates through the inner hidden sequences
+            raise NotImplementedError('asr_amd: a gradient on EqualScaleHyperLSTMLayer\'s inner hidden sequences is not built')
         return ScalingStepPair.backward(self, dY, need_dx)
 
     def _param_grads(self, ctx, rows, T, B):
@@ -548,6 +544,3 @@ class EqualScaleStepPair(ScalingStepPair):
             ops.gemm(P, gS, dp.g('S'), ta=True)
             ops.gemm(gW[:U], dp.p('Whh'), dp.g('P'), tb=True)
             ops.gemm(gS, dp.p('S'), dp.g('P'), tb=True, beta=1.0)
-            if self._ext[d] is not None:
-                ops.gemm(ctx['d'][d]['hid'][:, :U], self._ext[d], dp.g('P'), ta=True, beta=1.0)
-                self._ext[d] = None
