@@ -483,7 +483,8 @@ class EqualScaleStepPair(ScalingStepPair):
     The kernels therefore run a ScalingHyperLSTMLayer of inner width U with the folded weights; the inner hidden sequence
     is one GEMM after the loop, and the factors' gradients come from the folded ones by the product rule:
       dW_hh = P^T.dA,  dS = P^T.dS',  dP = dA.W_hh^T + dS'.S^T.
-    learn_init is not built: inner_hid_init lives in the projected space and has no pre-image under the fold."""
+    learn_init is not built: inner_hid_init lives in the projected space; its pre-image under the fold, h0.(P^T P)^-1.P^T,
+    costs an H x H inverse per training step and leaves a spurious dP term to cancel, for an option no caller sets."""
     kind = 'equalscale'
 
     def __init__(self, net, idx, D, N, H, clip, ndir, use_peepholes, use_layer_norm, learn_init):
