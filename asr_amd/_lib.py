@@ -81,6 +81,7 @@ _SIGS = {
     'asr_colreduce_static': (i32, [fp, i32, fp, i32, i32, i32, i32, fp, i32, fp]),
     'asr_bias_act': (i32, [fp, fp, i32, i32, i32, fp]),
     'asr_act_bwd': (i32, [fp, fp, i32, i32, i32, fp]),
+    'asr_act_eval': (i32, [i32, fp, fp, sz, fp]),
     'asr_rowscale': (i32, [fp, i32, fp, i32, i32, fp, i32, i32, i32, fp]),
     'asr_dropout': (i32, [fp, i32, fp, i32, i32, i32, f32, C.c_ulonglong, C.c_ulonglong, fp]),
     'asr_affine_rows': (i32, [fp, i32, fp, fp, fp, fp, i32, i32, i32, fp, i32, i32, i32, fp]),

@@ -722,3 +722,21 @@ extern "C" int asr_perm4(const float* src, float* dst, int rows, int N, int dir,
     ASR_CHECK_LAUNCH();
     return ASR_OK;
 }
+
+// ------------------------------------------------------------------ activation probe (tests only)
+// y[i] = the library's sigmoid (kind 0) / tanh (kind 1) / exp (kind 2) of x[i]: the very inline functions the
+// scans and the softmax use (common.h), so their accuracy can be measured against float64 from the host.
+__global__ void act_eval_kernel(int kind, const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = kind == 0 ? sigmoidf_(v) : kind == 1 ? tanhf_(v) : expf_(v);
+    }
+}
+extern "C" int asr_act_eval(int kind, const float* x, float* y, size_t n, hipStream_t stream) {
+    if (kind < 0 || kind > 2 || !x || !y) return ASR_ERR_ARG;
+    if (!n) return ASR_OK;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(act_eval_kernel, dim3(grid), dim3(256), 0, stream, kind, x, y, n);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}

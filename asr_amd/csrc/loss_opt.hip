@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(
     for (int w = 1; w < 4; ++w) am = amax_(am, ArgMax{smf[w], smi[w]});
     __syncthreads();
     float s = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) s += __expf(lr[c] - am.v);
+    for (int c = threadIdx.x; c < C; c += 256) s += expf_(lr[c] - am.v);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) smf[threadIdx.x >> 6] = s;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(
     if (dlogits) {
         const float g = m * scale;
         for (int c = threadIdx.x; c < C; c += 256) {
-            float p = __expf(lr[c] - am.v - lse);
+            float p = expf_(lr[c] - am.v - lse);
             dlogits[r * C + c] = (p - (c == y ? 1.f : 0.f)) * g;
         }
     }
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(
         float* orow = out + ((size_t)b * T + t) * C;
         for (int c = threadIdx.x; c < C; c += 256) {
             float lp = lr[c] - am.v - lse;
-            orow[c] = out_mode == 1 ? lp : __expf(lp);
+            orow[c] = out_mode == 1 ? lp : expf_(lp);
         }
     }
 }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += __expf(v[i][e] - am.v);        // padding lanes: exp(-inf) = 0
+        for (int e = 0; e < 4; ++e) s += expf_(v[i][e] - am.v);        // padding lanes: exp(-inf) = 0
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) smf[threadIdx.x >> 6] = s;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(
             if (gi < C4) {
                 f32x4 d;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = (__expf(v[i][e] - am.v - lse) - (gi * 4 + e == y ? 1.f : 0.f)) * g;
+                for (int e = 0; e < 4; ++e) d[e] = (expf_(v[i][e] - am.v - lse) - (gi * 4 + e == y ? 1.f : 0.f)) * g;
                 *(f32x4*)(dlogits + r * C + gi * 4) = d;
             }
         }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(
             if (gi < C4) {
                 f32x4 d;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float lp = v[i][e] - am.v - lse; d[e] = out_mode == 1 ? lp : __expf(lp); }
+                for (int e = 0; e < 4; ++e) { const float lp = v[i][e] - am.v - lse; d[e] = out_mode == 1 ? lp : expf_(lp); }
                 *(f32x4*)(orow + gi * 4) = d;
             }
         }

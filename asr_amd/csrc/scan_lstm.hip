@@ -467,10 +467,15 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
 // step t+1; one extra wait after the loop flushes the last step.  Same arithmetic as the generic kernel
 // except the order of the sums inside the cell-LN statistics.
 // ------------------------------------------------------------------------------------------------
-// tanh with the hardware reciprocal (1 ulp) instead of an IEEE division: 32 of them per lane and step sit on the
-// critical path of the kernel below; the saved r_out uses the same form, so state and saves agree bit for bit
+// 32 tanh per lane and step sit on the critical path of the kernel below; the saved r_out uses the same form,
+// so state and saves agree bit for bit.  Since round 3 this is the library's accurate tanhf_ (common.h); the
+// round-2 form (hardware reciprocal of __expf) is kept for the ASR_ACT=0 comparison build only.
 __device__ __forceinline__ float tanh_rcp_(float x) {
+#if ASR_ACT == 0
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+#else
+    return tanhf_(x);
+#endif
 }
 __global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves

@@ -83,6 +83,11 @@ int asr_colreduce(const float* x, int ldx, const float* y, int ldy, int rows, in
 int asr_colreduce_static(const float* x, int ldx, const float* y, int ldy, int rows, int n, int gmod,
                          float* out, int accumulate, asr_stream_t stream);
 
+/* Test probe: y[i] = the library's own sigmoid (kind 0) / tanh (kind 1) / exp (kind 2) of x[i], i.e. the inline
+ * forms every recurrence and the softmax use for T.nnet.sigmoid / T.tanh / T.exp (libs/lhuclstm_layers.py:93-108,
+ * libs/comp_graph_utils.py:35), so that their accuracy can be measured against float64 on the host. */
+int asr_act_eval(int kind, const float* x, float* y, size_t n, asr_stream_t stream);
+
 /* small MLP pieces: LHUC predictor libs/lhuclstm_layers.py:402-409, conditioning prologue
  * libs/lasagne_libs/recurrent_layers.py:1209-1211.  act: 0 identity, 1 relu, 2 tanh */
 int asr_bias_act(float* x, const float* bias, int rows, int n, int act, asr_stream_t stream);

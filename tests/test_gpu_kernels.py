@@ -252,3 +252,54 @@ def test_lstm_pack_modes_against_their_definitions():
         assert n == want.size
         assert np.array_equal(got, want.reshape(-1))
     assert L.asr_lstm_pack_w(Wd.data_ptr(), 8, 2, out.data_ptr(), None) == -1          # mode 2 needs N % 128 == 0
+
+
+@pytest.mark.parametrize('kind,name', [(0, 'sigmoid'), (1, 'tanh'), (2, 'exp')])
+def test_activation_accuracy(kind, name):
+    """The library's inline sigmoid / tanh / exp (asr_amd/csrc/common.h: every recurrence and the softmax use them
+    for T.nnet.sigmoid / T.tanh / T.exp, libs/lhuclstm_layers.py:93-108) against float64 over every 61st float32 bit
+    pattern (70 M arguments, both signs, all exponents): libm-grade = at most 3.5 ulp of the true value wherever that
+    value is a normal float32, tanh with RELATIVE accuracy near 0 (the round-2 forms were absolute there and lost
+    |x| * 2^-24 in the exponent's argument).  The measured maxima are written to gpurun_out/act_accuracy.jsonl."""
+    import json, os
+    from asr_amd import ops
+    worst, worst_x = 0.0, 0.0
+    step = 61
+    for lo in range(0, 1 << 32, 1 << 28):
+        bits = torch.arange(lo, lo + (1 << 28), step, dtype=torch.int64, device='cuda').to(torch.int32)
+        x = bits.view(torch.float32)
+        y = torch.empty_like(x)
+        ops.act_eval(kind, x, y)
+        xs, ys = x.cpu().numpy(), y.cpu().numpy()
+        keep = np.isfinite(xs)
+        if kind == 2:
+            keep &= np.abs(xs) < 87.0
+        xs, ys = xs[keep], ys[keep]
+        if xs.size == 0:
+            continue
+        xd = xs.astype(np.float64)
+        with np.errstate(over='ignore'):
+            ref = 1.0 / (1.0 + np.exp(-xd)) if kind == 0 else np.tanh(xd) if kind == 1 else np.exp(xd)
+        normal = np.abs(ref) >= 1.2e-38
+        ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+        err = np.abs(ys.astype(np.float64) - ref) / ulp
+        err = np.where(normal, err, 0.0)
+        assert np.isfinite(ys).all()
+        k = int(np.argmax(err))
+        if err[k] > worst:
+            worst, worst_x = float(err[k]), float(xs[k])
+    nanv = torch.full((4,), float('nan'), device='cuda')
+    out = torch.empty_like(nanv)
+    ops.act_eval(kind, nanv, out)
+    assert torch.isnan(out).all()                        # a diverged run must stay visible
+    inf = torch.tensor([float('inf'), -float('inf')], device='cuda')
+    out = torch.empty_like(inf)
+    ops.act_eval(kind, inf, out)
+    want = {0: [1.0, 0.0], 1: [1.0, -1.0], 2: [float('inf'), 0.0]}[kind]
+    assert out.cpu().tolist() == want
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'act_accuracy.jsonl'), 'a') as f:
+            f.write(json.dumps(dict(fn=name, max_ulp=worst, at=worst_x, arguments=(1 << 32) // step)) + '\n')
+    print('%s: max error %.2f ulp at x = %r' % (name, worst, worst_x))
+    assert worst <= 3.5, (name, worst, worst_x)
