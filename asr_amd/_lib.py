@@ -110,6 +110,7 @@ _SIGS = {
     'asr_lstm_scan_fwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),
     'asr_lstm_scan_bwd': (i32, [C.POINTER(LstmScanDesc), fp, sz, fp]),
     'asr_scan_status': (i32, [fp, i32]),
+    'asr_scan_set_chunks_per_wg': (i32, [i32]),
     'asr_perm4': (i32, [fp, fp, i32, i32, i32, fp]),
     'asr_hyper_pack_floats': (sz, [i32, i32, i32]),
     'asr_hyper_pack_w': (i32, [fp, fp, fp, fp, i32, i32, i32, fp, fp]),

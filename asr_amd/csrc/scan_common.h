@@ -13,6 +13,7 @@
 // workgroup leaves its time loop, and the host reports ASR_ERR_TIMEOUT from asr_scan_status().
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 
@@ -162,6 +163,16 @@ static inline bool scan_grid_fits(size_t nwg, size_t lds) {
     }
     const size_t per_cu = lds > 0 ? (160 * 1024) / lds : 1;
     return nwg <= (size_t)cus[dev] * (per_cu < 1 ? 1 : per_cu);
+}
+
+// ---- how many 16-row batch chunks one workgroup of a persistent scan may carry (teams of 4 waves on the same
+// resident weights, one publish / wait per exchange for all of them): 4 unless ASR_SCAN_NC (read once) or
+// asr_scan_set_chunks_per_wg (tests: the per-row results must not depend on it) says less
+extern int asr_scan_nc_cap_;
+static inline int scan_nc_cap() {
+    static const int env_nc = [] { const char* e = getenv("ASR_SCAN_NC"); const int v = e ? atoi(e) : 4;
+                                   return v >= 4 ? 4 : v >= 2 ? 2 : 1; }();
+    return asr_scan_nc_cap_ ? asr_scan_nc_cap_ : env_nc;
 }
 
 // ---- optional in-kernel phase stamps (diagnostic build only: -DSCAN_STAMPS; never in the product .so)

@@ -201,7 +201,14 @@ __device__ __forceinline__ float lhuc_drp(int kind, float v) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t per_wg) {
+// NC = 16-row batch chunks carried by one workgroup (1 or 2; the code is written for 4 as well, see hyper_launch): a workgroup is NC teams of 4 waves that run the
+// SAME program on consecutive chunks against the SAME resident weights (one copy in LDS) and share every
+// publish / wait of the step (one arrival per workgroup and exchange, payload NC times as large).  The matrix pipe
+// is 13-19 % busy and arithmetic ~ waits at NC = 1, so a second team's MFMAs and LDS / L2
+// latencies fall into the first team's waits.  Per-row results are bit-identical to NC = 1: a team's arithmetic
+// does not depend on NC.
+template <int NC>
+__global__ __launch_bounds__(256 * NC) void hyper_scan_fwd_kernel(HyperArgs A, size_t per_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     const int N = A.N, H = A.H, UH = A.UH, CR = 4 * UH, KS = A.KS, KSP = A.KSP, HS = A.HS, HSP = A.HSP;
@@ -209,23 +216,28 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
     float* Wm = smem;                                           // [KSP/4][64][4]
     float* Wg = Wm + (size_t)KSP * 64;                          // [(KSP+HSP)/4][4][CR][4]
     float* Wd = Wg + (size_t)(KSP + HSP) * 4 * CR;              // [3][HSP/4][64][4]
-    float* red = Wd + (size_t)3 * HSP * 64;                     // [3 tiles][4 waves][64][4]
-    int* flag = (int*)(red + 3 * 4 * 256);
+    const int team = threadIdx.x >> 8;                          // wave-uniform
+    float* red = Wd + (size_t)3 * HSP * 64 + (size_t)team * 3 * 4 * 256;   // per team [3 tiles][4 waves][64][4]
+    int* flag = (int*)(Wd + (size_t)3 * HSP * 64 + (size_t)NC * 3 * 4 * 256);
 
-    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
-    const int grp = chunk * A.ndir + dir;
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z * NC + team + A.chunk0;
+    const int grp = chunk * A.ndir + dir;                       // exchange buffers: one set per chunk and direction
+    const int sgrp = (blockIdx.z * NC + A.chunk0) * A.ndir + dir;   // arrival counters: one set per workgroup set
     const HyperDir& D = A.d[dir];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Roles (K quarter, epilogue duties) are rotated per team so that the teams' epilogue waves (role 0: main cell,
+    // role 1: hyper cell) sit on different SIMDs: hardware wave w runs on SIMD w % 4
+    const int lane = threadIdx.x & 63, wave = (int)(((threadIdx.x >> 6) + team * (4 / NC)) & 3);
+    const int tid = wave * 64 + lane;
     const int q = lane >> 4, bl = lane & 15;
     const int b = chunk * A.rpc + bl;
     const bool bvalid = (bl < A.rpc) && (b < B);
 
     GroupSync gs;
-    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, G, j, flag);
+    group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * per_wg);
         f32x4* dst = (f32x4*)smem;
-        for (size_t i = tid; i < per_wg / 4; i += 256) dst[i] = src[i];
+        for (size_t i = threadIdx.x; i < per_wg / 4; i += 256 * NC) dst[i] = src[i];
     }
     float* rex = A.rex + (size_t)grp * 2 * KSP * 64;
     float* hex = A.hex + (size_t)grp * 2 * HSP * 64;
@@ -276,6 +288,9 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
     }
 
     const int ks4 = KSP / 16, hs4 = HSP / 16;    // b128 groups per wave
+    // exchange-buffer operands requested together before the first MFMA that needs them: 8 blocks of h (4 with
+    // four teams per workgroup: 128 registers per wave there)
+    constexpr int BVC = NC == 4 ? 4 : 8;
     // inputs of the step, loaded one step ahead through walking per-lane pointers; branch-free (every
     // wave issues every load, non-owners read a dummy line) so that no join sits behind the loads
     const bool w0 = (wv == 0), w1 = (wv == 1);
@@ -312,16 +327,16 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         // MFMA so the exchange-buffer latency is paid once per chunk, not once per k-step.
         f32x4 am0 = {0, 0, 0, 0}, am1 = {0, 0, 0, 0}, ag0 = {0, 0, 0, 0}, ag1 = {0, 0, 0, 0};
         const int ic = (bl < CR ? bl : CR - 1);
-        const bool defer = (ks4 <= 8);
-        f32x4 bh[4], bv[8];
+        const bool defer = (ks4 <= BVC);
+        f32x4 bh[4], bv[BVC];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             bh[i] = ldb_sc1_f4(hex_rs, ex_voff, (unsigned)(par * HSP * 256) + (unsigned)(wv * hs4 + i) * 1024u);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < BVC; ++i)
             bv[i] = ldb_sc1_f4(rex_rs, ex_voff, (unsigned)(par * KSP * 256) + (unsigned)(wv * ks4 + i) * 1024u);
 #pragma unroll
-        for (int g4 = 0; g4 < 8; ++g4) {
+        for (int g4 = 0; g4 < BVC; ++g4) {
             if (g4 < ks4) {
                 const int s4 = wave * ks4 + g4;
                 const f32x4 gv = *(const f32x4*)(Wg + (((size_t)s4 * 4 + q) * CR + ic) * 4);
@@ -334,13 +349,13 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
                 }
             }
         }
-        for (int c0 = 8; c0 < ks4; c0 += 8) {           // N > 512: further chunks, main + hyper together
-            f32x4 bw[8];
+        for (int c0 = BVC; c0 < ks4; c0 += BVC) {       // N > 512: further chunks, main + hyper together
+            f32x4 bw[BVC];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < BVC; ++i)
                 bw[i] = ldb_sc1_f4(rex_rs, ex_voff, (unsigned)(par * KSP * 256) + (unsigned)(wv * ks4 + c0 + i) * 1024u);
 #pragma unroll
-            for (int g4 = 0; g4 < 8; ++g4) {
+            for (int g4 = 0; g4 < BVC; ++g4) {
                 if (c0 + g4 < ks4) {
                     const int s4 = wave * ks4 + c0 + g4;
                     const f32x4 av = *(const f32x4*)(Wm + ((size_t)s4 * 64 + lane) * 4);
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
         STAMP(3);
         if (defer) {                              // main tile under the exchange latency
 #pragma unroll
-            for (int g4 = 0; g4 < 8; ++g4) {
+            for (int g4 = 0; g4 < BVC; ++g4) {
                 if (g4 < ks4) {
                     const f32x4 av = *(const f32x4*)(Wm + ((size_t)(wave * ks4 + g4) * 64 + lane) * 4);
                     am0 = mfma4(av[0], bv[g4][0], am0); am1 = mfma4(av[1], bv[g4][1], am1);
@@ -488,38 +503,47 @@ __global__ __launch_bounds__(256) void hyper_scan_fwd_kernel(HyperArgs A, size_t
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+#define HYPER_BWD_STAGE (256 + 768 + 1024 + 256 + 1024)   // floats of per-team LDS staging in the backward kernel
 #define DAB 8      // da blocks per wave put in flight early (covers NBW <= 8, e.g. G = 128 with R = 8)
-__global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t per_wg) {
+template <int NC>
+__global__ __launch_bounds__(256 * NC) void hyper_scan_bwd_kernel(HyperArgs A, size_t per_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __builtin_amdgcn_s_setprio(3);
     const int N = A.N, H = A.H, UH = A.UH, HT = A.HT;
     const int T = A.T, B = A.B, G = A.G;
     const int S4P = ((H + 15) / 16) * 16;
     const int UHB = UH * 16;
+    constexpr int DABN = NC == 4 ? 4 : DAB;     // operand blocks in flight per wave (128 registers per wave at NC = 4)
     float* Wt = smem;                                   // [4 waves][NBW][64][4]
     float* Mb = Wt + (size_t)A.NBW * 1024;              // [HT][3][64][4]
     float* Rw = Mb + (size_t)HT * 3 * 256;              // [S4P/4][4][4+UH][4]
-    float* dal = Rw + (size_t)S4P * 4 * (4 + UH);                 // [16 cols][16 b]            da
+    const int team = threadIdx.x >> 8;                  // which of the NC chunks this 4-wave team carries (see forward)
+    float* stage = Rw + (size_t)S4P * 4 * (4 + UH);     // per team: HYPER_BWD_STAGE floats
+    float* dal = stage + (size_t)team * HYPER_BWD_STAGE;          // [16 cols][16 b]            da
     float* dDl = dal + 256;                             // [3][16 cols][16 b]         dD
     float* rsum = dDl + 768;                            // [16 pieces][4 units][16 b] W_h . da partial gather
     float* hsum = rsum + 1024;                          // [256]                      dhx gather partials
     float* red = hsum + 256;                            // [4 waves][64][4]           Rw product
-    int* flag = (int*)(red + 1024);
+    int* flag = (int*)(stage + (size_t)NC * HYPER_BWD_STAGE);
 
-    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z * NC + team + A.chunk0;
     const int grp = chunk * A.ndir + dir;
+    const int sgrp = (blockIdx.z * NC + A.chunk0) * A.ndir + dir;
     const HyperDir& D = A.d[dir];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Roles (K quarter, epilogue duties) are rotated per team so that the teams' epilogue waves (role 0: main cell,
+    // role 1: hyper cell) sit on different SIMDs: hardware wave w runs on SIMD w % 4
+    const int lane = threadIdx.x & 63, wave = (int)(((threadIdx.x >> 6) + team * (4 / NC)) & 3);
+    const int tid = wave * 64 + lane;
     const int q = lane >> 4, bl = lane & 15;
     const int b = chunk * A.rpc + bl;
     const bool bvalid = (bl < A.rpc) && (b < B);
 
     GroupSync gs;
-    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, G, j, flag);
+    group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * per_wg);
         f32x4* dst = (f32x4*)smem;
-        for (size_t i = tid; i < per_wg / 4; i += 256) dst[i] = src[i];
+        for (size_t i = threadIdx.x; i < per_wg / 4; i += 256 * NC) dst[i] = src[i];
     }
     float* dax = A.dax + (size_t)grp * 2 * G * 256;
     float* px = A.px + (size_t)grp * 2 * G * 1024;
@@ -717,7 +741,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         // ---- S3: gather dhx for own hyper units.  Behind its loads, the first DAB blocks per wave of
         // the all-gathered da are put in flight already (consumed after publish2): their latency
         // overlaps S3, the hyper cell and the second exchange
-        f32x4 dav[DAB];
+        f32x4 dav[DABN];
         const unsigned da_sbase = (unsigned)(((size_t)par * G + w_blk0) * 1024);
         {
             const int e = tid % UHB, s0 = tid / UHB, sstep = 256 / UHB;
@@ -737,7 +761,7 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             }
             STAMP(15);
 #pragma unroll
-            for (int i = 0; i < DAB; ++i)
+            for (int i = 0; i < DABN; ++i)
                 dav[i] = ldb_sc1_f4(dax_rs, (unsigned)(lane * 16), da_sbase + (unsigned)(i * 1024));
             hsum[tid] = acc;
         }
@@ -780,20 +804,20 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
         {
             f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < DAB; ++i) {
+            for (int i = 0; i < DABN; ++i) {
                 const bool ok = (i < NBW) && (w_bi0 + i < A.NBLK);
                 const f32x4 wt = *(const f32x4*)(Ww + ((size_t)(i < NBW ? i : 0) * 64 + lane) * 4);
                 const f32x4 dv = ok ? dav[i] : f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = mfma4(dv[e], wt[e], acc);
             }
-            for (int i0 = DAB; i0 < NBW; i0 += 8) {
-                f32x4 v[8];
+            for (int i0 = DABN; i0 < NBW; i0 += DABN) {
+                f32x4 v[DABN];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < DABN; ++i)
                     v[i] = ldb_sc1_f4(dax_rs, (unsigned)(lane * 16), da_sbase + (unsigned)((i0 + i) * 1024));
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < DABN; ++i) {
                     const bool ok = (i0 + i < NBW) && (w_bi0 + i0 + i < A.NBLK);
                     const f32x4 wt = *(const f32x4*)(Ww + ((size_t)(i0 + i < NBW ? i0 + i : 0) * 64 + lane) * 4);
                     const f32x4 dv = ok ? v[i] : f32x4{0, 0, 0, 0};
@@ -830,14 +854,14 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
             const int RR = 4 + UH;
             const int ir = (bl < RR ? bl : RR - 1);
             const int n4 = S4P / 16;
-            for (int c0 = 0; c0 < n4; c0 += 8) {
-                f32x4 bv[8];
+            for (int c0 = 0; c0 < n4; c0 += DABN) {
+                f32x4 bv[DABN];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)      // MFMA k = hyper unit 4*s4+q, step e = gate: dgx[par][unit][bl][0..3]
+                for (int i = 0; i < DABN; ++i)      // MFMA k = hyper unit 4*s4+q, step e = gate: dgx[par][unit][bl][0..3]
                     bv[i] = ldb_sc1_f4(dgx_rs, (unsigned)((q * 64 + bl * 4) * 4),
                                        (unsigned)(par * H * 256) + (unsigned)(wv * n4 + c0 + i) * 1024u);
 #pragma unroll
-                for (int g4i = 0; g4i < 8; ++g4i) {
+                for (int g4i = 0; g4i < DABN; ++g4i) {
                     if (c0 + g4i < n4) {
                         const int s4 = wave * n4 + c0 + g4i;
                         const f32x4 rv = *(const f32x4*)(Rw + (((size_t)s4 * 4 + q) * RR + ir) * 4);
@@ -904,6 +928,14 @@ __global__ __launch_bounds__(256) void hyper_scan_bwd_kernel(HyperArgs A, size_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// cap on the 16-row chunks one workgroup carries (scan_common.h: scan_nc_cap): 0 = ASR_SCAN_NC or the default
+int asr_scan_nc_cap_ = 0;
+extern "C" int asr_scan_set_chunks_per_wg(int nc) {
+    if (nc != 0 && nc != 1 && nc != 2 && nc != 4) return ASR_ERR_ARG;
+    asr_scan_nc_cap_ = nc;
+    return ASR_OK;
+}
+
 struct asr_hyper_scan_desc {
     int T, B, N, H, ndir;
     int step0, step1;            // steps [step0, step1) of the recurrence, in processing order; step1 == 0: all T
@@ -963,18 +995,18 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
     A.d[0] = d->dir[0]; A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
     const size_t per_wg = hyper_pack_floats_wg(A, backward);
-    size_t lds;
-    if (!backward) lds = (per_wg + 3 * 4 * 256) * 4 + 64;
-    else lds = (per_wg + 256 + 768 + 1024 + 256 + 1024) * 4 + 64;
-    if (lds > 160 * 1024) return ASR_ERR_ARG;
-    // Two workgroups fit one CU when each needs <= 80 KB of LDS.  Cutting the batch into 8-row chunks
-    // (two independent recurrences sharing a CU) was measured SLOWER (482 vs 325 ms/step on cfg3: the
-    // exchange is bound by memory-side traffic, which doubles), so it stays an experiment knob.
-    const int cap = (lds <= 80 * 1024) ? 512 : 256;
-    int rpc = 16;
-    if (const char* e = getenv("ASR_SCAN_RPC")) { const int v = atoi(e); if (v == 8 || v == 16) rpc = v; }
-    A.rpc = rpc;
-    const int nchunk = (d->B + rpc - 1) / rpc;
+    // LDS of a workgroup that carries nc chunks: the resident weights once, the staging buffers per team
+    auto lds_of = [&](int nc) -> size_t {
+        return !backward ? (per_wg + (size_t)nc * 3 * 4 * 256) * 4 + 64 : (per_wg + (size_t)nc * HYPER_BWD_STAGE) * 4 + 64;
+    };
+    if (lds_of(1) > 160 * 1024) return ASR_ERR_ARG;
+    // Knobs, read once per process (experiments only): ASR_SCAN_RPC = 8 cuts the batch into 8-row chunks (two
+    // independent recurrences sharing a CU: measured SLOWER, 482 vs 325 ms/step on cfg3, the exchange is bound by
+    // memory-side traffic, which doubles); ASR_SCAN_NC / asr_scan_set_chunks_per_wg cap the chunks per workgroup (1, 2 or 4).
+    static const int env_rpc = [] { const char* e = getenv("ASR_SCAN_RPC"); return e && atoi(e) == 8 ? 8 : 16; }();
+    const int env_nc = scan_nc_cap();
+    A.rpc = env_rpc;
+    const int nchunk = (d->B + A.rpc - 1) / A.rpc;
     const size_t ng = (size_t)d->ndir * ((d->B + 7) / 8);
     char* p = (char*)ws;
     A.sync = (unsigned*)p;  p += ng * SYNC_STRIDE * 4;
@@ -987,24 +1019,42 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
         A.dhx = (float*)p;  p += ng * 2 * (size_t)A.G * A.G * A.UH * 16 * 4;
         A.dgx = (float*)p;
     }
-    // one workgroup per CU whenever the grid fits the chip that way (the sc1 hand-off is measured for one workgroup per
-    // CU: MI355X_MICROARCH.md, table under 'Valid forms'): ask for more than half of a CU's 160 KB
-    if ((size_t)A.G * d->ndir * nchunk <= 256 && lds < 82 * 1024) lds = 82 * 1024;
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
     A.dbg = (unsigned long long*)((char*)ws + asr_hyper_scan_ws_bytes(d->T, d->B, d->N, d->H, d->ndir, backward) - STAMP_BYTES);
-    int cpl = cap / (A.G * d->ndir);
-    if (cpl < 1) cpl = 1;
-    if (cpl > nchunk) cpl = nchunk;
-    for (int c0 = 0; c0 < nchunk; c0 += cpl) {
-        const int nc = nchunk - c0 < cpl ? nchunk - c0 : cpl;
+    const int per_z = A.G * d->ndir;                     // workgroups of one z slice (all groups of NC chunks)
+    for (int c0 = 0; c0 < nchunk;) {
+        const int rem = nchunk - c0;
+        // chunks per workgroup: the smallest of 1, 2, 4 that covers what is left (a team beyond the batch finds
+        // every row invalid: it stores nothing and its exchange buffers exist, ceil(B/8) >= the padded chunk count
+        // for every B with 3 or more chunks); capped by ASR_SCAN_NC, by the rpc = 8 experiment and by the LDS
+        // (hyper scans: at most 2.  Four teams = 1024 threads leave 128 registers per wave; both kernels then spill
+        // 80-150 registers into scratch and ran slower than two launches of two teams: backward 93.8 vs 74.7 ms per
+        // 64-row layer, forward 56.3 vs 48.0, profiles/r03_batch_sweep.jsonl)
+        int nc = rem >= 2 ? 2 : 1;
+        if (nc > env_nc) nc = env_nc;
+        if (A.rpc != 16) nc = 1;
+        while (nc > 1 && lds_of(nc) > 160 * 1024) nc >>= 1;
+        if ((size_t)(c0 + nc) * d->ndir > ng) nc = 1;    // cannot happen for rpc = 16 (see above); stay inside ws
+        size_t lds = lds_of(nc);
+        // Two workgroups fit one CU when each needs <= 80 KB of LDS; one workgroup per CU whenever the grid fits the
+        // chip that way (the sc1 hand-off is measured for one workgroup per CU: MI355X_MICROARCH.md, table under
+        // 'Valid forms'): then ask for more than half of a CU's 160 KB
+        int zmax = ((lds <= 80 * 1024 && nc == 1) ? 512 : 256) / per_z;
+        if (zmax < 1) zmax = 1;
+        int nz = (rem + nc - 1) / nc;
+        if (nz > zmax) nz = zmax;
+        if ((size_t)per_z * nz <= 256 && lds < 82 * 1024) lds = 82 * 1024;
         A.chunk0 = c0;
-        dim3 grid(A.G, d->ndir, nc), block(256);
-        if (!scan_grid_fits((size_t)A.G * d->ndir * nc, lds)) return ASR_ERR_ARG;
-        const void* fn = backward ? (const void*)hyper_scan_bwd_kernel : (const void*)hyper_scan_fwd_kernel;
+        dim3 grid(A.G, d->ndir, nz), block(256 * nc);
+        if (!scan_grid_fits((size_t)per_z * nz, lds)) return ASR_ERR_ARG;
+        const void* fn;
+        if (!backward) fn = nc == 2 ? (const void*)hyper_scan_fwd_kernel<2> : (const void*)hyper_scan_fwd_kernel<1>;
+        else fn = nc == 2 ? (const void*)hyper_scan_bwd_kernel<2> : (const void*)hyper_scan_bwd_kernel<1>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASR_ERR_LAUNCH;
-        if (!backward) hipLaunchKernelGGL(hyper_scan_fwd_kernel, grid, block, lds, stream, A, per_wg);
-        else hipLaunchKernelGGL(hyper_scan_bwd_kernel, grid, block, lds, stream, A, per_wg);
+        void* kargs[] = {(void*)&A, (void*)&per_wg};
+        if (hipLaunchKernel(fn, grid, block, kargs, lds, stream) != hipSuccess) return ASR_ERR_LAUNCH;
         ASR_CHECK_LAUNCH();
+        c0 += nz * nc;
     }
     return ASR_OK;
 }

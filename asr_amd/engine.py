@@ -1092,6 +1092,21 @@ class Network(object):
                     self.grad_hook(*self.param_range('seqsum.'))
         self.join_deferred()
 
+    # ---- gradient accumulation over micro-batches: a batch whose saved BPTT state exceeds HBM (cfg3: 0.75 MB per
+    # (t, b) row over 4 layer pairs, i.e. B = 128 x T = 2900 would need 276 GB) runs as several loss()/backward()
+    # passes; the caller sets `world` to the number of equal parts so that every part is scaled by 1/B_total
+    # (libs/comp_graph_utils.py:40), and the sum is what theano.grad of the whole batch gives.
+    def grad_accumulate(self, first):
+        if getattr(self, '_gacc', None) is None:
+            self._gacc = torch.empty_like(self.store.g)
+        if first:
+            self._gacc.copy_(self.store.g)
+        else:                                        # sgd step with lr = -1: acc <- acc + g, exact
+            ops.opt_step(0, self._gacc, self.store.g, None, None, -1.0, 0.0, 0.0, 0.0)
+
+    def grad_accumulated(self):
+        self.store.g.copy_(self._gacc)
+
     def adam_update(self, lr, b1=0.9, b2=0.999, eps=1e-8, want_sqrt=True):
         """libs/lasagne_libs/updates.py:587-617 on the flat buffer + grads_norm
         (libs/comp_graph_utils.py:77; TBPTT trainer returns the un-rooted sum, :111)."""

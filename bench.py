@@ -279,6 +279,14 @@ def main():
                          'into three bf16 parts (default), f32 = fp32 MFMA throughout, bf16 = the optional bf16 mode')
     ap.add_argument('--bf16', action='store_true', help='same as --precision bf16: reported as dtype bf16-gemm, '
                                                         'never the default')
+    ap.add_argument('--batch', type=int, default=BATCH, help='rows per GPU (weak scaling: the headline line uses 16)')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong-scaling leg (SURVEY 8d cfg3 row, README.md:6-7,11-12: global batch 128): rows per GPU = '
+                         'this / --gpus, "scaling": "strong"; the scans carry up to four 16-row chunks per workgroup')
+    ap.add_argument('--micro-batch', type=int, default=64,
+                    help='rows per loss()/backward() pass: more rows per GPU than this run as length-sorted micro-batches '
+                         'with gradient accumulation (the saved BPTT state of cfg3 is 0.75 MB per frame row: 64 rows x '
+                         '2700 frames = 130 GB of the 288 GB)')
     ap.add_argument('--forward-only', action='store_true',
                     help='with --cfg 1/2/4: time the forward pass alone (BASELINE configs[0] is a forward-only case)')
     ap.add_argument('--selftest-cpu', action='store_true',
@@ -305,6 +313,12 @@ def main():
     if args.cfg != 3:
         return other_config(args, rank, world, dev)
 
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit('bench.py: --global-batch %d is not a multiple of --gpus %d' % (args.global_batch, world))
+        B_local = args.global_batch // world
+    else:
+        B_local = args.batch
     net = build_deep_hyperlstm('hyper', None, None, N_IN, N_LAYERS, N_UNITS, N_HYPER, N_Z, N_OUT, 1.0,
                                True, 0, device=dev, seed=1234)
     if args.bf16:
@@ -314,17 +328,40 @@ def main():
     from asr_amd import ops
     precision = ops.PRECISION
     ar = dp.GradAllReduce(net)
+    n_micro = (B_local + args.micro_batch - 1) // args.micro_batch
+    if n_micro > 1 and (world > 1 or B_local % n_micro):
+        raise SystemExit('bench.py: micro-batches need one GPU and equal parts (the bucketed all-reduce fires inside '
+                         'backward(), before an accumulation could happen)')
     batches = []
     for i in range(args.pool):
-        b = workloads.make_batch(3, BATCH, seed_offset=1000 * rank + i)
-        batches.append((torch.from_numpy(b['x']).to(dev), torch.from_numpy(b['mask']).to(dev),
-                        torch.from_numpy(b['y']).to(dev), b['frames'], b['x'].shape[1]))
+        b = workloads.make_batch(3, B_local, seed_offset=1000 * rank + i)
+        parts = []
+        if n_micro > 1:        # rows sorted by length (a permutation of the batch), each part padded to its own longest row
+            order = np.argsort(-b['lengths'], kind='stable')
+            Bm = B_local // n_micro
+            for k in range(n_micro):
+                rows = order[k * Bm:(k + 1) * Bm]
+                Tk = int(b['lengths'][rows].max())
+                parts.append(tuple(torch.from_numpy(np.ascontiguousarray(b[n][rows, :Tk])).to(dev) for n in ('x', 'mask', 'y')))
+        else:
+            parts.append(tuple(torch.from_numpy(b[n]).to(dev) for n in ('x', 'mask', 'y')))
+        batches.append((parts, b['frames']))
 
     def step(i):
-        x, m, y, frames, T = batches[i % len(batches)]
-        net.loss(x, m, y, m)
-        net.backward()
-        ar.finish()
+        parts, frames = batches[i % len(batches)]
+        if len(parts) == 1:
+            x, m, y = parts[0]
+            net.loss(x, m, y, m)
+            net.backward()
+            ar.finish()
+        else:
+            net.world = len(parts)                       # loss scale 1 / (rows of all parts)
+            for k, (x, m, y) in enumerate(parts):
+                net.loss(x, m, y, m)
+                net.backward()
+                net.grad_accumulate(first=(k == 0))
+            net.grad_accumulated()
+            net.world = 1
         net.adam_update(1e-3)
         return frames
 
@@ -360,7 +397,7 @@ def main():
         fwd = [(rows, ndir, e0.elapsed_time(e1)) for k, bw, rows, ndir, e0, e1 in ev if k == 'hyper' and not bw]
         ms = float(np.mean([t for _, _, t in bwd]))
         byts = float(np.mean([rows * ndir * scan_bytes_per_row_dir(True) for rows, ndir, _ in bwd]))
-        steps_per_launch = float(np.mean([rows / BATCH for rows, _, _ in bwd]))
+        steps_per_launch = float(np.mean([rows / B_local for rows, _, _ in bwd]))
         ach = byts / (ms * 1e-3) / 1e9
         traffic = None       # HBM/fabric bytes per launch of the same kernel from the committed PMC passes
         pj = os.path.join(ROOT, 'profiles', 'r02g_pmc_hyper_scan_bwd.json')
@@ -376,12 +413,13 @@ def main():
                     scan_share_of_step=float(sum(t for _, _, t in bwd + fwd)) / (dt * 1e3))
         out = dict(metric='train frames/sec (node) 4x512 HyperLSTM', value=frames / dt, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
-                   higher_is_better=True, scaling='weak', vs_baseline=None,
+                   higher_is_better=True, scaling='strong' if args.global_batch else 'weak', vs_baseline=None,
                    dtype='bf16-gemm/f32-scan' if precision == 'bf16' else 'f32', data='synthetic',
                    config=dict(workload='cfg3: 4x512 HyperLSTM (H=128,Z=64) bidirectional, C=3436, '
                                         'two concatenated WSJ-shaped utterances per row, fwd+BPTT+'
-                                        'all-reduce+Adam', per_gpu_batch=BATCH, global_batch=BATCH * world,
-                               parallelism='dp%d' % world,
+                                        'all-reduce+Adam', per_gpu_batch=B_local, global_batch=B_local * world,
+                               parallelism='dp%d' % world, micro_batches=n_micro,
+                               scan_chunks_per_workgroup=min(2, (min(B_local, args.micro_batch) + 15) // 16),
                                gemm={'f32x3': 'fp32-grade: operands split into 3 bf16 parts, 6 bf16-MFMA partial '
                                               'products, fp32 accumulate (error vs float64 below the fp32 MFMA kernel)',
                                      'f32': 'v_mfma_f32_32x32x2_f32', 'bf16': 'operands rounded to bf16'}[precision]),

@@ -199,6 +199,11 @@ int asr_lstm_scan_fwd(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, as
 int asr_lstm_scan_bwd(const asr_lstm_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 /* after the stream is synchronised: ASR_ERR_TIMEOUT if any group's bounded wait expired */
 int asr_scan_status(const void* ws, int ngroups);
+/* How many 16-row batch chunks one workgroup of a persistent scan carries per step against the same resident
+ * weights (1, 2 or 4; 0 = default: up to 4, or ASR_SCAN_NC).  theano.scan steps any batch size at once
+ * (libs/lasagne_libs/hyper_lhuc_layers.py:493-500); here batches above 16 rows ride the same per-step exchanges.
+ * Per-row results do not depend on the setting (tests/test_gpu_multichunk.py); process-wide, not thread-safe. */
+int asr_scan_set_chunks_per_wg(int nc);
 
 /* (rows,4N) gate-major [i|f|c|o] <-> gate-interleaved col = unit*4+gate (dir 0: to interleaved,
  * 1: back).  The concatenation of the reference's per-gate matrices, libs/lhuclstm_layers.py:58-60,
