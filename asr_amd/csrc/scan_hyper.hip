@@ -1024,24 +1024,22 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     const int per_z = A.G * d->ndir;                     // workgroups of one z slice (all groups of NC chunks)
     for (int c0 = 0; c0 < nchunk;) {
         const int rem = nchunk - c0;
-        // chunks per workgroup: the smallest of 1, 2, 4 that covers what is left (a team beyond the batch finds
-        // every row invalid: it stores nothing and its exchange buffers exist, ceil(B/8) >= the padded chunk count
-        // for every B with 3 or more chunks); capped by ASR_SCAN_NC, by the rpc = 8 experiment and by the LDS
+        // chunks per workgroup: 1 or 2, capped by ASR_SCAN_NC, by the rpc = 8 experiment and by the LDS
         // (hyper scans: at most 2.  Four teams = 1024 threads leave 128 registers per wave; both kernels then spill
         // 80-150 registers into scratch and ran slower than two launches of two teams: backward 93.8 vs 74.7 ms per
         // 64-row layer, forward 56.3 vs 48.0, profiles/r03_batch_sweep.jsonl)
-        int nc = rem >= 2 ? 2 : 1;
-        if (nc > env_nc) nc = env_nc;
+        // Teams only for chunks that do not fit the launch as workgroups of their own (one per CU)
+        const int zcap = 256 / per_z > 0 ? 256 / per_z : 1;
+        int nc = (rem > zcap && env_nc >= 2) ? 2 : 1;
         if (A.rpc != 16) nc = 1;
         while (nc > 1 && lds_of(nc) > 160 * 1024) nc >>= 1;
-        if ((size_t)(c0 + nc) * d->ndir > ng) nc = 1;    // cannot happen for rpc = 16 (see above); stay inside ws
         size_t lds = lds_of(nc);
-        // Two workgroups fit one CU when each needs <= 80 KB of LDS; one workgroup per CU whenever the grid fits the
-        // chip that way (the sc1 hand-off is measured for one workgroup per CU: MI355X_MICROARCH.md, table under
-        // 'Valid forms'): then ask for more than half of a CU's 160 KB
+        // Two workgroups fit one CU when each needs <= 80 KB of LDS (only taken with teams switched off); one
+        // workgroup per CU whenever the grid fits the chip that way (the sc1 hand-off is measured for one workgroup
+        // per CU: MI355X_MICROARCH.md, table under 'Valid forms'): then ask for more than half of a CU's 160 KB
         int zmax = ((lds <= 80 * 1024 && nc == 1) ? 512 : 256) / per_z;
         if (zmax < 1) zmax = 1;
-        int nz = (rem + nc - 1) / nc;
+        int nz = nc == 2 ? rem / 2 : rem;
         if (nz > zmax) nz = zmax;
         if ((size_t)per_z * nz <= 256 && lds < 82 * 1024) lds = 82 * 1024;
         A.chunk0 = c0;

@@ -210,21 +210,31 @@ __device__ __forceinline__ void combine_sums4(const float* st, int KS, int tid, 
     for (int g = 0; g < 4; ++g) { s14[g] = scr[(g * 16 + bl) * 2]; s24[g] = scr[(g * 16 + bl) * 2 + 1]; }
 }
 
+// NC (all four scan kernels below) = 16-row batch chunks carried by one workgroup: NC teams of 4 waves run the same
+// program on consecutive chunks against the same resident weights and share every publish / wait of the step (see
+// hyper_scan_fwd_kernel, scan_hyper.hip).  Roles (K quarter, epilogue duty) are rotated per team so that the teams'
+// epilogue waves sit on different SIMDs.  Per-row results do not depend on NC.
+#define TEAM_IDS_(NC_)                                                                                   \
+    const int team = threadIdx.x >> 8;                                                                   \
+    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z * NC_ + team + A.chunk0;              \
+    const int grp = chunk * A.ndir + dir;                                 /* exchange buffers: per chunk */ \
+    const int sgrp = (blockIdx.z * NC_ + A.chunk0) * A.ndir + dir;        /* arrival counters: per workgroup set */ \
+    const LstmDir& D = A.d[dir];                                                                         \
+    const int lane = threadIdx.x & 63, wave = (int)(((threadIdx.x >> 6) + team * (4 / NC_)) & 3);        \
+    const int tid = wave * 64 + lane;
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int UT>
-__global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
+template <int UT, int NC>
+__global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // [UT][KSP/4][64][4]
-    float* red = Wl + (size_t)UT * A.KSP * 64;          // [UT][4 waves][64][4]
-    int* flag = (int*)(red + UT * 4 * 256);
+    float* red = Wl + (size_t)UT * A.KSP * 64 + (threadIdx.x >> 8) * UT * 1024;   // per team [UT][4 waves][64][4]
+    int* flag = (int*)(Wl + (size_t)UT * A.KSP * 64 + NC * UT * 1024);
 
-    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
-    const int grp = chunk * A.ndir + dir;
-    const LstmDir& D = A.d[dir];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TEAM_IDS_(NC)
     const int q = lane >> 4, bl = lane & 15;
     const int b0 = chunk * 16;
     const int b = b0 + bl;
@@ -232,13 +242,13 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     const int N = A.N, KS = A.KS, KSP = A.KSP, T = A.T, B = A.B;
 
     GroupSync gs;
-    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
+    group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, A.G, j, flag);
 
     // resident weights
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * UT * KSP * 64);
         f32x4* dst = (f32x4*)Wl;
-        for (int i = tid; i < UT * KSP * 16; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < UT * KSP * 16; i += 256 * NC) dst[i] = src[i];
     }
     float* rex = A.rex + (size_t)grp * 2 * KSP * 64;
     float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 128 : nullptr;
@@ -477,29 +487,27 @@ __device__ __forceinline__ float tanh_rcp_(float x) {
     return tanhf_(x);
 #endif
 }
-__global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) {
+template <int NC>
+__global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // [KSP/4][64][4]
-    float* red = Wl + (size_t)A.KSP * 64;               // [4 waves][64][4]
-    int* flag = (int*)(red + 4 * 256);
-    float* scr = (float*)flag + 16;                     // [2][4 waves][16 rows] statistics partials
+    float* red = Wl + (size_t)A.KSP * 64 + (threadIdx.x >> 8) * 1024;     // per team [4 waves][64][4]
+    int* flag = (int*)(Wl + (size_t)A.KSP * 64 + NC * 1024);
+    float* scr = (float*)flag + 16 + (threadIdx.x >> 8) * 256;            // per team [2][4 waves][16 rows] statistics partials
 
-    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
-    const int grp = chunk * A.ndir + dir;
-    const LstmDir& D = A.d[dir];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TEAM_IDS_(NC)
     const int q = lane >> 4, bl = lane & 15;
     const int b = chunk * 16 + bl;
     const bool bvalid = b < A.B;
     const int N = A.N, KS = A.KS, KSP = A.KSP, T = A.T, B = A.B;
 
     GroupSync gs;
-    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
+    group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, A.G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * KSP * 64);
         f32x4* dst = (f32x4*)Wl;
-        for (int i = tid; i < KSP * 16; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < KSP * 16; i += 256 * NC) dst[i] = src[i];
     }
     // exchange layout [parity][tile][c | o][batch][unit]
     float* rex = A.rex + (size_t)grp * 4 * KSP * 64;
@@ -717,30 +725,27 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cln_kernel(LstmScanArgs A) 
 //   2. cell / gate gradients for its units (+ LN backward with two small stat exchanges)
 //   3. partial dr_{t-1}[b, all k] = da[b, own cols] . W'[k, own cols]^T  -> publish per destination
 // ------------------------------------------------------------------------------------------------
-template <int UT>
-__global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
+template <int UT, int NC>
+__global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wb = smem;                                   // [UT][KT][64][4]
-    float* dal = Wb + (size_t)UT * A.KT * 256;          // [UT][16 cols][16 b]
+    float* dal = Wb + (size_t)UT * A.KT * 256 + (threadIdx.x >> 8) * UT * 1280;   // per team [UT][16 cols][16 b]
     float* rsum = dal + UT * 256;                       // [UT][16 sg][16 b][4]
-    int* flag = (int*)(rsum + UT * 1024);
+    int* flag = (int*)(Wb + (size_t)UT * A.KT * 256 + NC * UT * 1280);
 
-    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
-    const int grp = chunk * A.ndir + dir;
-    const LstmDir& D = A.d[dir];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TEAM_IDS_(NC)
     const int q = lane >> 4, bl = lane & 15;
     const int b = chunk * 16 + bl;
     const bool bvalid = b < A.B;
     const int N = A.N, KS = A.KS, KT = A.KT, T = A.T, B = A.B, G = A.G;
 
     GroupSync gs;
-    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
+    group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, A.G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * UT * KT * 256);
         f32x4* dst = (f32x4*)Wb;
-        for (int i = tid; i < UT * KT * 64; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < UT * KT * 64; i += 256 * NC) dst[i] = src[i];
     }
     float* dex = A.dex + (size_t)grp * 2 * KS * G * 64;
     float* sta = A.sta ? A.sta + (size_t)grp * 2 * KS * 128 : nullptr;
@@ -978,20 +983,17 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_kernel(LstmScanArgs A) {
 // groups both tensors are stored in.  Same arithmetic as lstm_scan_bwd_kernel up to the order of the sums.
 // ------------------------------------------------------------------------------------------------
 #define L2D_R 8
-template <int PG>                                       // PG: per-gate LN statistics (compile time: the row-LN
-__global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A) {   // path keeps scalar statistics)
+template <int PG, int NC>                               // PG: per-gate LN statistics (compile time: the row-LN
+__global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A) {   // path keeps scalar statistics)
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TW = A.KS / (4 * L2D_R);                  // source tiles per wave (1..4)
     float* Wb = smem;                                   // [4 waves][TW][2 unit tiles][64][4]
-    float* red2 = Wb + (size_t)TW * 2048;               // [4 waves][2][64][4]
+    float* red2 = Wb + (size_t)TW * 2048 + (threadIdx.x >> 8) * 2304;     // per team [4 waves][2][64][4]
     float* scr = red2 + 2048;                           // combine_sums scratch
-    int* flag = (int*)(scr + 256);
+    int* flag = (int*)(Wb + (size_t)TW * 2048 + NC * 2304);
 
-    const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z + A.chunk0;
-    const int grp = chunk * A.ndir + dir;
-    const LstmDir& D = A.d[dir];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TEAM_IDS_(NC)
     const int q = lane >> 4, bl = lane & 15;
     const int b = chunk * 16 + bl;
     const bool bvalid = b < A.B;
@@ -999,11 +1001,11 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_ln2d_kernel(LstmScanArgs A)
     const int ub = j / L2D_R, kr = j % L2D_R;
 
     GroupSync gs;
-    group_sync_init(gs, A.sync + (size_t)grp * SYNC_STRIDE, A.G, j, flag);
+    group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, A.G, j, flag);
     {
         const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * TW * 2048);
         f32x4* dst = (f32x4*)Wb;
-        for (int i = tid; i < TW * 512; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < TW * 512; i += 256 * NC) dst[i] = src[i];
     }
     // exchange buffers inside the (larger) dex region: dhx [2][KS tiles][16 b][16 cols], px [2][G][2][16 b][16 u]
     float* dhx = A.dex + (size_t)grp * 2 * KS * G * 64;
@@ -1297,44 +1299,58 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     A.dbg = (unsigned long long*)((char*)ws + asr_lstm_scan_ws_bytes(d->T, d->B, d->N, d->ndir, backward) - STAMP_BYTES);
     if (hipMemsetAsync(A.sync, 0, ng * SYNC_STRIDE * 4, stream) != hipSuccess) return ASR_ERR_LAUNCH;
 
-    size_t lds;
     // cell-LN nets at UT = 1, N <= 512: the forward kernel with one exchange fewer per step
-    const bool fused_cln = !backward && A.cell_ln && UT == 1 && A.KSP / 16 <= 8;
-    lds = ((size_t)UT * A.KSP * 64 + UT * 4 * 256) * 4 + 64 + (fused_cln ? 1024 : 0);
+    // ... for batches whose chunks all fit one launch as workgroups of their own.  With two teams that kernel needs
+    // ~330 registers per lane against 256 and spills (cfg2 at 32 rows: 114.6 k frames/s, against 146.2 k with the
+    // generic kernel's teams and 96-114 k with one launch per chunk), so larger batches take the generic kernel for
+    // EVERY chunk: the two kernels sum the cell-LN statistics in different orders, and a batch's rows must not
+    // depend on which launch carried them.
+    const bool fused_cln = !backward && A.cell_ln && UT == 1 && A.KSP / 16 <= 8 && nchunk_total <= cpl;
     const bool ln2d = backward && UT == 1 && asr_lstm_bwd_pack_mode(d->N, d->ndir, d->ln_kind) == 2;
-    if (ln2d) lds = ((size_t)(A.KS / 32) * 2048 + 2048 + 256) * 4 + 64;
-    else if (backward) lds = ((size_t)UT * A.KT * 256 + UT * 256 + UT * 1024) * 4 + 64;
-    if (lds > 160 * 1024) return ASR_ERR_ARG;
-    // one workgroup per CU (what the sc1 hand-off is measured for, MI355X_MICROARCH.md 'Valid forms'): a launch
-    // never exceeds 256 workgroups, so asking for more than half of a CU's 160 KB spreads them one per CU
-    if (lds < 82 * 1024) lds = 82 * 1024;
+    // LDS of a workgroup whose nc teams carry nc chunks: the resident weights once, the staging buffers per team
+    auto lds_of = [&](int nc) -> size_t {
+        if (ln2d) return ((size_t)(A.KS / 32) * 2048 + (size_t)nc * 2304) * 4 + 64;
+        if (backward) return ((size_t)UT * A.KT * 256 + (size_t)nc * UT * 1280) * 4 + 64;
+        return ((size_t)UT * A.KSP * 64 + (size_t)nc * UT * 1024) * 4 + 64 + (fused_cln ? 1024 * nc : 0);
+    };
+    if (lds_of(1) > 160 * 1024) return ASR_ERR_ARG;
+    const int nc_cap = scan_nc_cap() >= 2 ? 2 : 1;
 
-    for (int c0 = 0; c0 < nchunk_total; c0 += cpl) {
-        const int nc = (nchunk_total - c0 < cpl) ? nchunk_total - c0 : cpl;
+    for (int c0 = 0; c0 < nchunk_total;) {
+        const int rem = nchunk_total - c0;
+        // chunks that do not fit one launch as workgroups of their own (cpl z slices) ride as teams of two inside a
+        // workgroup instead of waiting for a launch of their own
+        int nc = (rem > cpl && nc_cap >= 2 && lds_of(2) <= 160 * 1024) ? 2 : 1;
+        int nz = nc == 2 ? rem / 2 : rem;
+        if (nz > cpl) nz = cpl;
+        size_t lds = lds_of(nc);
+        // one workgroup per CU (what the sc1 hand-off is measured for, MI355X_MICROARCH.md 'Valid forms'): a launch
+        // never exceeds 256 workgroups, so asking for more than half of a CU's 160 KB spreads them one per CU
+        if (lds < 82 * 1024) lds = 82 * 1024;
         LstmScanArgs Al = A;
-        Al.nchunk = nc;
+        Al.nchunk = nz * nc;
         Al.chunk0 = c0;
-        dim3 grid(A.G, d->ndir, nc), block(256);
-        if (!scan_grid_fits((size_t)A.G * d->ndir * nc, lds)) return ASR_ERR_ARG;
-#define LAUNCH_(K, U) \
-        do { if (hipFuncSetAttribute((const void*)K<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-                 return ASR_ERR_LAUNCH; \
-             hipLaunchKernelGGL((K<U>), grid, block, lds, stream, Al); } while (0)
+        dim3 grid(A.G, d->ndir, nz), block(256 * nc);
+        if (!scan_grid_fits((size_t)A.G * d->ndir * nz, lds)) return ASR_ERR_ARG;
+        const void* fn = nullptr;
+#define PICK_NC_(...) (nc == 2 ? (const void*)__VA_ARGS__, 2> : (const void*)__VA_ARGS__, 1>)
         if (!backward) {
-            if (fused_cln) {
-                if (hipFuncSetAttribute((const void*)lstm_scan_fwd_cln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds) != hipSuccess) return ASR_ERR_LAUNCH;
-                hipLaunchKernelGGL(lstm_scan_fwd_cln_kernel, grid, block, lds, stream, Al);
-            } else if (UT == 1) LAUNCH_(lstm_scan_fwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_fwd_kernel, 2);
-            else LAUNCH_(lstm_scan_fwd_kernel, 4);
+            if (fused_cln) fn = (const void*)lstm_scan_fwd_cln_kernel<1>;
+            else if (UT == 1) fn = PICK_NC_(lstm_scan_fwd_kernel<1);
+            else if (UT == 2) fn = PICK_NC_(lstm_scan_fwd_kernel<2);
+            else fn = PICK_NC_(lstm_scan_fwd_kernel<4);
         } else {
-            if (ln2d) {
-                if (A.per_gate) LAUNCH_(lstm_scan_bwd_ln2d_kernel, 1); else LAUNCH_(lstm_scan_bwd_ln2d_kernel, 0);
-            } else if (UT == 1) LAUNCH_(lstm_scan_bwd_kernel, 1); else if (UT == 2) LAUNCH_(lstm_scan_bwd_kernel, 2);
-            else LAUNCH_(lstm_scan_bwd_kernel, 4);
+            if (ln2d) fn = A.per_gate ? PICK_NC_(lstm_scan_bwd_ln2d_kernel<1) : PICK_NC_(lstm_scan_bwd_ln2d_kernel<0);
+            else if (UT == 1) fn = PICK_NC_(lstm_scan_bwd_kernel<1);
+            else if (UT == 2) fn = PICK_NC_(lstm_scan_bwd_kernel<2);
+            else fn = PICK_NC_(lstm_scan_bwd_kernel<4);
         }
-#undef LAUNCH_
+#undef PICK_NC_
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASR_ERR_LAUNCH;
+        void* kargs[] = {(void*)&Al};
+        if (hipLaunchKernel(fn, grid, block, kargs, lds, stream) != hipSuccess) return ASR_ERR_LAUNCH;
         ASR_CHECK_LAUNCH();
+        c0 += nz * nc;
     }
     return ASR_OK;
 }

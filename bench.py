@@ -189,6 +189,7 @@ def other_config(args, rank, world, dev):
     from asr_amd import builders, dp, gating_hyper_nets as G, workloads
     from asr_amd.utils import gen_win
     cfg = args.cfg
+    BATCH = args.batch                 # rows per GPU (module default 16)
     tb = []
     if cfg == 1:
         net = builders.build_deep_lstm(None, None, 123, 3, 256, 0, 61, 1.0, True, False, 0, device=dev, seed=1)
@@ -397,20 +398,44 @@ def main():
         fwd = [(rows, ndir, e0.elapsed_time(e1)) for k, bw, rows, ndir, e0, e1 in ev if k == 'hyper' and not bw]
         ms = float(np.mean([t for _, _, t in bwd]))
         byts = float(np.mean([rows * ndir * scan_bytes_per_row_dir(True) for rows, ndir, _ in bwd]))
-        steps_per_launch = float(np.mean([rows / B_local for rows, _, _ in bwd]))
+        B_part = B_local // n_micro                       # rows of one loss()/backward() pass
+        steps_per_launch = float(np.mean([rows / B_part for rows, _, _ in bwd]))
         ach = byts / (ms * 1e-3) / 1e9
-        traffic = None       # HBM/fabric bytes per launch of the same kernel from the committed PMC passes
-        pj = os.path.join(ROOT, 'profiles', 'r02g_pmc_hyper_scan_bwd.json')
-        if os.path.exists(pj):
-            with open(pj) as f:
+        # HBM / fabric bytes per launch of the same kernel from the newest committed PMC passes (tools/profile_bench.sh:
+        # FETCH_SIZE and WRITE_SIZE in runs of their own): 2 x FETCH + WRITE, the gfx950 correction of
+        # MI355X_MICROARCH.md (FETCH_SIZE tallies wide reads at half their bytes).  The file names the library it was
+        # measured on; `traffic_same_library` says whether that is the library loaded now.
+        traffic = None; traffic_src = None; same_lib = None
+        import glob, hashlib
+        pjs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hyper_scan_bwd.json')))
+        if pjs and B_local == BATCH:
+            with open(pjs[-1]) as f:
                 pm = json.load(f)
-            traffic = (pm['fetch_size_kb_per_launch'] + pm['write_size_kb_per_launch']) * 1024.0
+            traffic = (2.0 * pm['fetch_size_kb_per_launch'] + pm['write_size_kb_per_launch']) * 1024.0
+            traffic_src = os.path.relpath(pjs[-1], ROOT)
+            from asr_amd import _lib
+            if pm.get('library_sha256'):
+                with open(_lib.LIB_PATH, 'rb') as f:
+                    same_lib = hashlib.sha256(f.read()).hexdigest() == pm['library_sha256']
+        us_step = ms * 1e3 / steps_per_launch
         roof = dict(bound='hbm', kernel='hyper_scan_bwd_kernel', achieved=ach, peak=8000.0, unit='GB/s',
-                    frac=ach / 8000.0, traffic=traffic, algorithmic_bytes_per_launch=byts,
-                    avg_launch_ms=ms,
-                    us_per_timestep=ms * 1e3 / steps_per_launch,
+                    frac=ach / 8000.0, traffic=traffic, traffic_source=traffic_src, traffic_same_library=same_lib,
+                    algorithmic_bytes_per_launch=byts, avg_launch_ms=ms, us_per_timestep=us_step,
                     fwd_kernel_avg_launch_ms=float(np.mean([t for _, _, t in fwd])),
                     scan_share_of_step=float(sum(t for _, _, t in bwd + fwd)) / (dt * 1e3))
+        # The scan is latency-bound, not byte-bound: next to the HBM fraction, the floor that two
+        # dependent chip-wide exchanges and the step's dependent MFMA chain set, from tracked measurements
+        lf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_latency_floor.json')))
+        if lf:
+            with open(lf[-1]) as f:
+                fl = json.load(f)
+            k = fl['per_step']['hyper_scan_bwd_kernel']
+            floor_us = k['dependent_exchanges'] * fl['exchange_us'] + k['mfma_per_wave'] * fl['mfma_issue_ns'] * 1e-3
+            launches = ((B_part + 15) // 16 + 1) // 2     # kernel launches per scan: two 16-row chunks per workgroup
+            roof.update(latency_floor_us=floor_us, frac_of_latency_floor=floor_us / (us_step / launches),
+                        latency_floor_source=os.path.relpath(lf[-1], ROOT),
+                        latency_floor_terms=dict(exchanges_per_step=k['dependent_exchanges'], exchange_us=fl['exchange_us'],
+                                                 dependent_mfma_per_wave=k['mfma_per_wave'], mfma_issue_ns=fl['mfma_issue_ns']))
         out = dict(metric='train frames/sec (node) 4x512 HyperLSTM', value=frames / dt, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
                    higher_is_better=True, scaling='strong' if args.global_batch else 'weak', vs_baseline=None,

@@ -82,33 +82,41 @@ def test_hyperlstm_more_than_16_rows_vs_oracle(B):
     run_case(net, b)
 
 
-@pytest.mark.parametrize('kind', ['lstm', 'ln_lstmp', 'ivec_ln'])
-@pytest.mark.parametrize('B', [40, 67])
+@pytest.mark.parametrize('kind', ['lstm', 'lstm_uni_1024', 'ln_lstmp', 'ln_lstmp_gate_ln', 'ivec_ln'])
+@pytest.mark.parametrize('B', [40, 64])
 def test_lstm_family_chunks_per_workgroup_bit_identical(kind, B):
+    """Full layer widths, so that a 16-row chunk fills the chip (512 units bidirectional = 256 workgroups) and further
+    chunks ride as teams: plain LSTM (generic kernels), 1024 units unidirectional (two tiles per workgroup), LN-LSTMP
+    (cell-LN forward kernel + 2-D backward), its per-gate-LN sibling (per-gate statistics), i-vector cond-LN."""
     from asr_amd import builders, gating_hyper_nets as G
     ck = None
     if kind == 'lstm':
-        net = builders.build_deep_lstm(None, None, 9, 2, 64, 0, 11, 1.0, True, False, 0, device=DEV, seed=3)
+        net = builders.build_deep_lstm(None, None, 9, 2, 512, 0, 11, 1.0, True, False, 0, device=DEV, seed=3)
+    elif kind == 'lstm_uni_1024':
+        net = builders.build_deep_lstm(None, None, 9, 1, 1024, 0, 11, 1.0, False, False, 0, device=DEV, seed=3)
     elif kind == 'ln_lstmp':
-        net = G.deep_projection_ln_lstm_model(None, None, 9, 11, 2, 32, 64, grad_clipping=1.0, dropout=0.0,
+        net = G.deep_projection_ln_lstm_model(None, None, 9, 11, 2, None, 512, grad_clipping=1.0, dropout=0.0,
                                               device=DEV, seed=3)
+    elif kind == 'ln_lstmp_gate_ln':
+        net = G.deep_prj_lstm_ln_model_v2(None, None, 9, 11, 2, 512, 256, grad_clipping=1.0, dropout=0.0,
+                                          device=DEV, seed=3)
     else:
-        net, _ = G.deep_projection_ivector_ln_model(None, None, None, 9, 11, 2, 2, 8, 64, 1.0, 0.0, cond_dim=5,
+        net, _ = G.deep_projection_ivector_ln_model(None, None, None, 9, 11, 2, 2, 8, 512, 1.0, 0.0, cond_dim=5,
                                                     device=DEV, seed=3)
         ck = 'ivec'
-    perturb_params(net, 12, 0.05)
-    b = make_batch(np.random.default_rng(B + 7), B, 29, 9, 11, I=5 if ck else 0)
+    perturb_params(net, 12, 0.02)
+    b = make_batch(np.random.default_rng(B + 7), B, 14, 9, 11, I=5 if ck else 0)
     _same_for_every_nc(net, b, ck)
 
 
 @pytest.mark.parametrize('kind', ['lstm', 'ln_lstmp'])
-def test_lstm_family_67_rows_vs_oracle(kind):
+def test_lstm_family_40_rows_full_width_vs_oracle(kind):
     from asr_amd import builders, gating_hyper_nets as G
     if kind == 'lstm':
-        net = builders.build_deep_lstm(None, None, 9, 2, 32, 0, 11, 1.0, True, False, 0, device=DEV, seed=4)
+        net = builders.build_deep_lstm(None, None, 9, 1, 512, 0, 11, 1.0, True, False, 0, device=DEV, seed=4)
     else:
-        net = G.deep_projection_ln_lstm_model(None, None, 9, 11, 2, 16, 32, grad_clipping=1.0, dropout=0.0,
+        net = G.deep_projection_ln_lstm_model(None, None, 9, 11, 1, None, 512, grad_clipping=1.0, dropout=0.0,
                                               device=DEV, seed=4)
-    perturb_params(net, 13, 0.05)
-    b = make_batch(np.random.default_rng(77), 67, 19, 9, 11)
+    perturb_params(net, 13, 0.02)
+    b = make_batch(np.random.default_rng(77), 40, 12, 9, 11)
     run_case(net, b, calibrate=(kind != 'lstm'))

@@ -3,7 +3,7 @@
 # PMC passes and two MFMA-utilisation passes (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots).
 # usage: tools/profile_bench.sh <tag>
 set -e
-TAG=${1:-r01}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -4,7 +4,7 @@
   <tag>_bench_pmc_mfma.csv       per kernel: derived MfmaUtil (%) and the raw MFMA counters, average per launch
   <tag>_pmc_hyper_scan_bwd.json  the dominant kernel's two figures, read by bench.py for roofline.traffic
 usage: python tools/summarize_prof.py <prof_dir> <tag> <out_dir>"""
-import csv, glob, json, os, shutil, sys
+import csv, glob, hashlib, json, os, shutil, sys
 from collections import defaultdict
 
 
@@ -55,11 +55,14 @@ def main():
                                                 ','.join('%.0f' % raw[c].get(k, (0, 0))[1] for c in raw)))
     for kname in ('hyper_scan_bwd_kernel', 'hyper_scan_fwd_kernel'):
         if kname in fe and kname in wr:
+            lib = os.environ.get('ASR_AMD_LIB') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'asr_amd', 'libasr_amd.so')
             json.dump({'kernel': kname,
+                       'library_sha256': hashlib.sha256(open(lib, 'rb').read()).hexdigest(),
                        'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1, ' + tag,
                        'fetch_size_kb_per_launch': fe[kname][1], 'write_size_kb_per_launch': wr[kname][1],
+                       'traffic_bytes_per_launch': (2 * fe[kname][1] + wr[kname][1]) * 1024.0,
                        'note': 'bytes = KB*1024; FETCH_SIZE on gfx950 counts wide coalesced reads at half their bytes '
-                               '(MI355X_MICROARCH.md HBM): traffic_bytes = 2*FETCH + WRITE is the upper estimate, FETCH + WRITE the lower'},
+                               '(MI355X_MICROARCH.md HBM): traffic_bytes = 2*FETCH + WRITE as that guide prescribes'},
                       open(os.path.join(out, '%s_pmc_%s.json' % (tag, kname.replace('_kernel', ''))), 'w'), indent=1)
 
 
