@@ -27,6 +27,10 @@ struct LstmDir {
     const float* beta_c;     // (N)
     const float* c0;         // (B,N) or null
     const float* r0;         // (B,N) or null
+    const float* a0;         // (B,4N) or null: the recurrent pre-activation h_{-1}.W_h of the FIRST step, used in place of
+                             // r0.W' there.  A stateful projected layer carries hid_init = h of the previous window,
+                             // projected with the W_p of THAT window (libs/lhuclstm_layers.py:313-319); after an optimiser
+                             // step r0.(W_p.W_h) with the new W_p is not h_init.W_h any more (forward scans only)
     float* r_out;            // (T,B,ld_r) state r after each step (time order)
     int ld_r;
     float* gates;            // (T,B,4N) post-activation i,f,g,o       (null: inference)
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A)
         if (wave < UT) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(wave * 4 + w) * 64 + lane) * 4);
+            if (step == 0 && D.a0) a4 = *(const f32x4*)(D.a0 + (size_t)bq * 4 * N + col4);
         }
         float rs_a = 0.f;
         f32x4 rs_a4 = {0, 0, 0, 0};
@@ -1305,7 +1310,8 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     // generic kernel's teams and 96-114 k with one launch per chunk), so larger batches take the generic kernel for
     // EVERY chunk: the two kernels sum the cell-LN statistics in different orders, and a batch's rows must not
     // depend on which launch carried them.
-    const bool fused_cln = !backward && A.cell_ln && UT == 1 && A.KSP / 16 <= 8 && nchunk_total <= cpl;
+    const bool fused_cln = !backward && A.cell_ln && UT == 1 && A.KSP / 16 <= 8 && nchunk_total <= cpl &&
+                           !d->dir[0].a0 && !(d->ndir > 1 && d->dir[1].a0);
     const bool ln2d = backward && UT == 1 && asr_lstm_bwd_pack_mode(d->N, d->ndir, d->ln_kind) == 2;
     // LDS of a workgroup whose nc teams carry nc chunks: the resident weights once, the staging buffers per team
     auto lds_of = [&](int nc) -> size_t {

@@ -238,7 +238,8 @@ class LstmPair(object):
         self.dirs = [_mk_lstm_family(net.store, 'L%d.%d.' % (idx, d), kind, D, N, P,
                                      self.ln_kind == 1, I, F, npu, npl) for d in range(ndir)]
         self.reverse = [False, True][:ndir]
-        self.state = [None] * ndir           # TBPTT (c, r) per direction
+        self.state = [None] * ndir           # TBPTT (c, r, h) per direction; h = the PROJECTED hidden state as the
+                                             # window that produced it projected it (== r without a projection)
 
     def describe(self):
         out = {}
@@ -273,10 +274,12 @@ class LstmPair(object):
             if not (self.stateful and d == 0):
                 self.state[d] = None
             elif self.state[d] is not None and self.state[d][0].shape[0] == batch_size:
-                self.state[d][0].zero_(); self.state[d][1].zero_()
+                for t_ in self.state[d]:
+                    t_.zero_()
             else:
                 self.state[d] = (torch.zeros(batch_size, self.N, device=dev),
-                                 torch.zeros(batch_size, self.N, device=dev))
+                                 torch.zeros(batch_size, self.N, device=dev)) + \
+                                ((torch.zeros(batch_size, self.P, device=dev),) if self.P else ())
 
     def _buf(self, name, rows, cols, zero=False):
         return self.net.arena.mat('L%d.%s' % (self.idx, name), rows, cols, zero)
@@ -306,6 +309,12 @@ class LstmPair(object):
             if st is not None:           # this window's initial state, kept for its backward pass
                 c['c0'] = self._buf('c0_%d' % d, B, N); c['r0'] = self._buf('r0_%d' % d, B, N)
                 c['c0'].copy_(st[0]); c['r0'].copy_(st[1])
+                if P and len(st) > 2:
+                    # hid_init is the projected state as the previous window left it (libs/lhuclstm_layers.py:313-319,
+                    # :230-235), not r0 re-projected with a W_p that an optimiser step has moved since: the first
+                    # step's recurrent pre-activation is h0 . W_h, handed to the scan as a0
+                    c['h0'] = self._buf('h0_%d' % d, B, P); c['h0'].copy_(st[2])
+                    c['a0'] = ops.gemm(c['h0'], dp.p('Wh'), self._buf('a0_%d' % d, B, 4 * N))
             if self.kind == 'lhuc':
                 if net.seqsum is not None:                  # SeqSumLHUCLSTMLayer, :487-489
                     emb = net.seqsum.emb
@@ -372,6 +381,8 @@ class LstmPair(object):
                 Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
             if 'c0' in c:
                 Dd.c0 = c['c0'].data_ptr(); Dd.r0 = c['r0'].data_ptr()
+                if 'a0' in c:
+                    Dd.a0 = c['a0'].data_ptr()
             direct = (not P) and self.kind != 'lhuc'       # scan writes straight into Y's column block
             if direct:
                 R = Y[:, d * N:(d + 1) * N]
@@ -405,6 +416,7 @@ class LstmPair(object):
             Yd = Y[:, d * Pout:(d + 1) * Pout]
             if P and self.kind != 'lhuc':
                 ops.gemm(c['R'], dp.p('Wp'), Yd)
+                hid = Yd
             elif self.kind == 'lhuc':
                 if P:
                     hid = self._buf('hid%d' % d, rows, P)
@@ -413,6 +425,13 @@ class LstmPair(object):
                     hid = c['R']
                 c['hid'] = hid
                 ops.rowscale(hid, hid.stride(0), c['sf'], B, True, Yd, Yd.stride(0), rows, Pout)
+            else:
+                hid = None
+            if P and self.stateful and self.state[d] is not None and len(self.state[d]) > 2:
+                last = T - 1                   # the projected state, with THIS window's W_p (:313-319)
+                if self.context:
+                    last = (T if T < self.context else self.context) - 1
+                self.state[d][2].copy_(hid[last * B:(last + 1) * B])
         return Y
 
     def backward(self, dY, need_dx=True):
@@ -528,8 +547,11 @@ class LstmPair(object):
             if 'r0' in c:
                 # the carried hid_init = r0.W_p is a stored constant (libs/lhuclstm_layers.py:230-235): its
                 # first-step term belongs to W_h alone, not to W_p through the folded matrix
-                h0 = self._buf('h0_%d' % d, B, P)
-                ops.gemm(c['r0'], dp.p('Wp'), h0)
+                if 'h0' in c:
+                    h0 = c['h0']
+                else:                          # an injected (c, r) state (tests): h0 = r0 . W_p of the current weights
+                    h0 = self._buf('h0_%d' % d, B, P)
+                    ops.gemm(c['r0'], dp.p('Wp'), h0)
                 ops.gemm(h0, first, dp.g('Wh'), ta=True, beta=1.0)
         if dp.has('b'):
             ops.colreduce(dG, dp.g('b'), rows, 4 * N)

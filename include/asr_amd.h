@@ -165,6 +165,9 @@ typedef struct asr_lstm_dir {
     const float* beta_c;      /* (N) */
     const float* c0;          /* (B,N) initial cell or NULL (zeros) */
     const float* r0;          /* (B,N) initial r    or NULL (zeros) */
+    const float* a0;          /* (B,4N) or NULL: h_init . W_h, the first step's recurrent pre-activation, taken in place
+                               * of r0 . W' there (forward): TBPTTLSTMLayer's hid_init is the PROJECTED state of the
+                               * previous window, libs/lhuclstm_layers.py:313-319,230-235 */
     float* r_out;             /* (T,B,ld_r) */
     int ld_r;
     float* gates;             /* (T,B,4N) saved for BPTT (NULL = inference) */

@@ -192,6 +192,46 @@ def test_tbptt_windows_carry_state():
             assert np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax) < 1e-4
 
 
+@pytest.mark.parametrize('use_ln', [False, True])
+def test_tbptt_projected_state_survives_an_optimiser_step(use_ln):
+    """exp_deep_lstm2_tbptt.py takes one optimiser step per window, and TBPTTLSTMLayer hands the PROJECTED hidden
+    state hid_out[:, last] to the next window (libs/lhuclstm_layers.py:313-319,230-235): the state was projected with
+    the W_p from BEFORE the step.  Three windows of a stateful LSTMP (with and without layer norm), an Adam step with
+    a large learning rate after each (the oracle then takes the updated weights): every window's loss and gradients against the oracle.  (Carrying
+    r and re-projecting it with the updated W_p -- the round-2 form -- differs by r0.dW_p in every window after the
+    first: with lr = 0.05 that is far above the tolerance.)"""
+    from asr_amd.builders import build_deep_lstm_tbptt
+    ctxt = 4
+    net, tb = build_deep_lstm_tbptt(None, None, 5, 2, 8, 4, 6, 3, ctxt, 0.0, False, use_ln, 0, device=_dev(), seed=6)
+    perturb_params(net, 13, 0.15)
+    b = make_batch(np.random.default_rng(15), 3, 12, 5, 6, lengths=[12, 3, 9])
+    vals = [v.astype(np.float64) for v in net.get_all_param_values()]
+    onet = O.OracleNetwork(net.describe(), vals)
+    for l in tb:
+        l.reset(3)
+    for l in onet.tbptt_layers():
+        l.reset(3)
+    dev = net.device
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    full = (b['x'], b['mask'], b['x'], b['mask'], b['y'], b['mask'])
+    for w, win in enumerate(O.gen_win(full, ctxt, 0)):
+        xw, mw, _, _, yw, tmw = win
+        ce, ok, pred = net.loss(t_(xw), t_(mw), t_(yw), t_(tmw), None, True, ctxt)
+        net.backward()
+        net.check_status()
+        oc, os_, opred, ograds = onet.loss_and_grads(xw, mw, yw, tmw, None, context=ctxt)
+        assert abs(ce.item() - os_) <= 2e-5 * max(abs(os_), 1.0), (w, ce.item(), os_)
+        gmax = max(np.max(np.abs(g)) for g in ograds)
+        for n, g, og in zip([n for n, _ in net.param_names_shapes()], net.get_all_grad_values(), ograds):
+            assert np.max(np.abs(g - og)) / (np.max(np.abs(og)) + 1e-3 * gmax) < 1e-4, (w, n)
+        net.adam_update(0.05)
+        # the oracle takes the weights the HIP path now holds (its own Adam step would land within rounding of them,
+        # but sign-like first Adam steps amplify 1e-7 gradient differences): what is under test is the carried state
+        for v, nv in zip(onet.values, net.get_all_param_values()):
+            v[...] = nv
+    assert w == 2
+
+
 @pytest.mark.parametrize('is_bidir', [False, True])
 @pytest.mark.parametrize('clip', [0.0, 0.05])
 def test_hyperlstm_small(is_bidir, clip):
