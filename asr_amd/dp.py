@@ -3,6 +3,8 @@
 only exchange step of the path is the SUM all-reduce of the flat fp32 gradient, bucketed per layer
 in reverse topological order and launched on a side stream as soon as that layer's BPTT has produced
 its gradients, so it overlaps with the BPTT of the layers below.  Batch rows never move."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -17,7 +19,13 @@ class GradAllReduce(object):
         self.cuda = net.device.type == 'cuda'
         self.stream = torch.cuda.Stream(device=net.device) if self.cuda else None
         self.pending = []
-        if self.world > 1:
+        # ASR_DP_OVERLAP=0: no bucket leaves before the last BPTT scan has finished; finish() then reduces the whole
+        # flat gradient in one collective on the main stream.  The fallback for a node on which RCCL's kernels and the
+        # persistent scans (256 workgroups, one per CU, 82 KB of LDS each) do not share the chip well: a bucket's
+        # all-reduce kernel can only run beside a scan on the LDS and wave slots that scan leaves (78 KB, 28 waves per
+        # CU), and a scan that started first is never pre-empted; measured nowhere yet (no multi-GPU node this round).
+        self.overlap = os.environ.get('ASR_DP_OVERLAP', '1') != '0'
+        if self.world > 1 and self.overlap:
             net.grad_hook = self.bucket_ready
 
     def bucket_ready(self, lo, hi):
@@ -33,7 +41,11 @@ class GradAllReduce(object):
             self.pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Before the optimiser step: make the main stream wait for every bucket."""
+        """Before the optimiser step: make the main stream wait for every bucket (or, without overlap, reduce the
+        whole gradient now)."""
+        if self.world > 1 and not self.overlap:
+            dist.all_reduce(self.net.store.g, op=dist.ReduceOp.SUM, group=self.group)
+            return
         for w in self.pending:
             w.wait()
         self.pending = []

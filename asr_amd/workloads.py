@@ -27,10 +27,32 @@ CFG = {1: dict(D=123, C=61, seed=1001, I=0), 2: dict(D=123, C=3436, seed=1002, I
        5: dict(D=123, C=3436, seed=1005, I=100)}
 
 
-def make_batch(cfg, B=16, seed_offset=0, max_len=None):
+def length_sorted_batches(cfg, B, n_batches, cache=1024, seed_offset=0):
+    """Utterance lengths of `n_batches` batches of B rows drawn the way the reference's LengthSortTransformer forms
+    them (data/transformers.py:15-63; create_ivector_datastream(..., length_sort=True, min_after_cache=1024),
+    data/fuel_utils.py:94-109): a cache of >= `cache` shuffled utterances is sorted by length and cut into consecutive
+    batches.  The batches of a cache are then visited in a seeded random order, so that a run does not see them
+    shortest first.  Returns a list of int64 arrays."""
+    c = CFG[cfg]
+    rng = np.random.default_rng(c['seed'] + 7919 + seed_offset)
+    out = []
+    while len(out) < n_batches:
+        n = max(cache, B)
+        n = ((n + B - 1) // B) * B
+        lens = np.sort(lengths_for(cfg, rng, n), kind='stable')
+        cuts = [lens[i:i + B] for i in range(0, n, B)]
+        rng.shuffle(cuts)
+        out.extend(cuts)
+    return out[:n_batches]
+
+
+def make_batch(cfg, B=16, seed_offset=0, max_len=None, lengths=None):
+    """lengths: take these utterance lengths (length_sorted_batches, or a rank's share of a global batch) instead of
+    drawing B fresh ones; features / targets are seeded by seed_offset as before."""
     c = CFG[cfg]
     rng = np.random.default_rng(c['seed'] + seed_offset)
-    lens = lengths_for(cfg, rng, B)
+    lens = lengths_for(cfg, rng, B) if lengths is None else np.asarray(lengths, np.int64)
+    B = len(lens)
     if max_len:
         lens = np.minimum(lens, max_len)
     T = int(lens.max())

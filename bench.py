@@ -288,6 +288,10 @@ def main():
                     help='rows per loss()/backward() pass: more rows per GPU than this run as length-sorted micro-batches '
                          'with gradient accumulation (the saved BPTT state of cfg3 is 0.75 MB per frame row: 64 rows x '
                          '2700 frames = 130 GB of the 288 GB)')
+    ap.add_argument('--length-sort', action='store_true',
+                    help='form the global batches the way the reference\'s LengthSortTransformer does (a cache of 1024 '
+                         'utterances sorted by length, cut into consecutive batches; data/transformers.py:15-63, off by '
+                         'default there as here); each rank takes a contiguous block of the sorted global batch')
     ap.add_argument('--forward-only', action='store_true',
                     help='with --cfg 1/2/4: time the forward pass alone (BASELINE configs[0] is a forward-only case)')
     ap.add_argument('--selftest-cpu', action='store_true',
@@ -334,8 +338,15 @@ def main():
         raise SystemExit('bench.py: micro-batches need one GPU and equal parts (the bucketed all-reduce fires inside '
                          'backward(), before an accumulation could happen)')
     batches = []
+    sorted_lens = workloads.length_sorted_batches(3, B_local * world, args.pool) if args.length_sort else None
+    t_local = []                                      # padded length of every pool batch on this rank
     for i in range(args.pool):
-        b = workloads.make_batch(3, B_local, seed_offset=1000 * rank + i)
+        if sorted_lens is not None:                   # the same global batch on every rank; this rank's block of it
+            b = workloads.make_batch(3, B_local, seed_offset=1000 * rank + i,
+                                     lengths=sorted_lens[i][rank * B_local:(rank + 1) * B_local])
+        else:
+            b = workloads.make_batch(3, B_local, seed_offset=1000 * rank + i)
+        t_local.append(int(b['lengths'].max()))
         parts = []
         if n_micro > 1:        # rows sorted by length (a permutation of the batch), each part padded to its own longest row
             order = np.argsort(-b['lengths'], kind='stable')
@@ -391,6 +402,17 @@ def main():
         fsum = tt[1:2].clone(); dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
         dt = tmax.item(); frames = fsum.item()
 
+    # what a step waits for: every rank's scans run for its own padded length, the step ends with the slowest rank
+    steps_T = torch.tensor([float(t_local[(args.warmup + i) % len(t_local)]) for i in range(args.steps)],
+                           dtype=torch.float64, device=dev)
+    if world > 1:
+        allT = [torch.zeros_like(steps_T) for _ in range(world)]
+        dist.all_gather(allT, steps_T)
+        allT = torch.stack(allT).cpu().numpy()
+    else:
+        allT = steps_T.cpu().numpy()[None, :]
+    rank_T_mean = [float(v) for v in allT.mean(axis=1)]
+    rank_idle_frac = float(1.0 - allT.mean() / allT.max(axis=0).mean())
     if rank == 0:
         ev = net.scan_events
         net.scan_events = None
@@ -444,12 +466,18 @@ def main():
                                         'two concatenated WSJ-shaped utterances per row, fwd+BPTT+'
                                         'all-reduce+Adam', per_gpu_batch=B_local, global_batch=B_local * world,
                                parallelism='dp%d' % world, micro_batches=n_micro,
+                               batching='length-sorted cache of 1024 utterances (LengthSortTransformer)' if args.length_sort
+                               else 'independent random batches per rank (reference default: length_sort=False)',
                                scan_chunks_per_workgroup=min(2, (min(B_local, args.micro_batch) + 15) // 16),
                                gemm={'f32x3': 'fp32-grade: operands split into 3 bf16 parts, 6 bf16-MFMA partial '
                                               'products, fp32 accumulate (error vs float64 below the fp32 MFMA kernel)',
                                      'f32': 'v_mfma_f32_32x32x2_f32', 'bf16': 'operands rounded to bf16'}[precision]),
                    roofline=roof)
         out.update(clock.summary())
+        # padded frames per rank and step; rank_idle_frac = 1 - mean over ranks / max over ranks of them: the share of
+        # a step the average rank spends waiting for the rank with the longest utterance (0 on one GPU)
+        out['rank_T_mean'] = rank_T_mean
+        out['rank_idle_frac'] = rank_idle_frac
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(net)
         print(json.dumps(out))

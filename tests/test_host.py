@@ -359,6 +359,70 @@ def test_gloo_world2_bucketed_allreduce(tmp_path):
         assert 'rank %d ok' % r in o
 
 
+_GLOO_STATUS_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from asr_amd import dp
+from asr_amd._lib import AsrError
+
+class Store(object):
+    pass
+
+class FakeNet(object):
+    """engine.Network as GradAllReduce sees it; check_status() fails on the rank named by FAIL_RANK."""
+    def __init__(self, rank):
+        self.device = torch.device('cpu'); self.rank = rank
+        self.store = Store(); self.store.g = torch.full((64,), float(rank + 1)); self.store.p = torch.zeros(64)
+        self.world = 1; self.grad_hook = None
+    def check_status(self):
+        if os.environ.get('FAIL_RANK') == str(self.rank):
+            raise AsrError('persistent scan gave up: ASR_ERR_TIMEOUT (-4)')
+
+rank = int(os.environ['RANK']); world = int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+net = FakeNet(rank)
+ar = dp.GradAllReduce(net)
+assert ar.overlap == (os.environ.get('ASR_DP_OVERLAP', '1') != '0')
+assert (net.grad_hook is not None) == ar.overlap
+if net.grad_hook:
+    net.grad_hook(0, 64)
+ar.finish()
+assert net.store.g.tolist() == [3.0] * 64            # summed with or without overlap
+stepped = False
+try:
+    ar.agree_on_status()
+    net.store.p -= 0.1 * net.store.g                 # the optimiser step: only if EVERY rank's scans were fine
+    stepped = True
+except AsrError as e:
+    print('rank', rank, 'raised:', e)
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'stepped' if stepped else 'skipped')
+'''
+
+
+@pytest.mark.parametrize('fail_rank,overlap', [('1', '1'), ('0', '0'), ('', '0')])
+def test_gloo_world2_status_agreement_and_no_overlap_fallback(tmp_path, fail_rank, overlap):
+    """dp.GradAllReduce.agree_on_status: when ONE rank's persistent scan reports a timeout, BOTH ranks raise before
+    the optimiser step (no rank steps on garbage, none is left inside a collective); with ASR_DP_OVERLAP=0 the whole
+    gradient is reduced in finish() and the sums are the same."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_GLOO_STATUS_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29537', WORLD_SIZE='2', FAIL_RANK=fail_rank,
+               ASR_DP_OVERLAP=overlap)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        if fail_rank:
+            assert 'rank %d raised' % r in o and 'rank %d skipped' % r in o, o
+            if str(r) != fail_rank:
+                assert 'another rank' in o, o
+        else:
+            assert 'rank %d stepped' % r in o, o
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` outside torch.distributed.run spawns two ranks itself (before any GPU
     call) and relays rank 0's single JSON line; rehearsed on the CPU over gloo (--selftest-cpu)."""
