@@ -52,6 +52,15 @@ class GradAllReduce(object):
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
 
+    def suspend_overlap(self):
+        """Gradient accumulation over micro-batches: buckets must not leave before the last micro-batch has been
+        added, so backward() gets no hook and the caller reduces the accumulated gradient with reduce_all()."""
+        self.net.grad_hook = None
+
+    def reduce_all(self):
+        if self.world > 1:
+            dist.all_reduce(self.net.store.g, op=dist.ReduceOp.SUM, group=self.group)
+
     def agree_on_status(self):
         """Called between the gradient exchange and the optimiser step: one host sync, then every rank
         learns whether ANY rank's persistent scan gave up (ASR_ERR_TIMEOUT), and all of them raise

@@ -284,10 +284,12 @@ def main():
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong-scaling leg (SURVEY 8d cfg3 row, README.md:6-7,11-12: global batch 128): rows per GPU = '
                          'this / --gpus, "scaling": "strong"; the scans carry up to four 16-row chunks per workgroup')
-    ap.add_argument('--micro-batch', type=int, default=64,
-                    help='rows per loss()/backward() pass: more rows per GPU than this run as length-sorted micro-batches '
-                         'with gradient accumulation (the saved BPTT state of cfg3 is 0.75 MB per frame row: 64 rows x '
-                         '2700 frames = 130 GB of the 288 GB)')
+    ap.add_argument('--micro-batch', type=int, default=32,
+                    help='rows per loss()/backward() pass: more rows per GPU than this run as micro-batches of the batch '
+                         'sorted by length, each padded to its own longest row, with gradient accumulation.  32 rows = '
+                         'one launch per scan (two 16-row chunks per workgroup); measured at a global batch of 128 on '
+                         'one GPU: 218.5 k frames/s with 32, 193.5 k with 64 (and 128 rows at once do not fit: the saved '
+                         'BPTT state of cfg3 is 0.75 MB per frame row)')
     ap.add_argument('--length-sort', action='store_true',
                     help='form the global batches the way the reference\'s LengthSortTransformer does (a cache of 1024 '
                          'utterances sorted by length, cut into consecutive batches; data/transformers.py:15-63, off by '
@@ -334,9 +336,10 @@ def main():
     precision = ops.PRECISION
     ar = dp.GradAllReduce(net)
     n_micro = (B_local + args.micro_batch - 1) // args.micro_batch
-    if n_micro > 1 and (world > 1 or B_local % n_micro):
-        raise SystemExit('bench.py: micro-batches need one GPU and equal parts (the bucketed all-reduce fires inside '
-                         'backward(), before an accumulation could happen)')
+    if n_micro > 1 and B_local % n_micro:
+        raise SystemExit('bench.py: %d rows per GPU do not split into %d equal micro-batches' % (B_local, n_micro))
+    if n_micro > 1:
+        ar.suspend_overlap()        # the accumulated gradient is reduced once, after the last micro-batch
     batches = []
     sorted_lens = workloads.length_sorted_batches(3, B_local * world, args.pool) if args.length_sort else None
     t_local = []                                      # padded length of every pool batch on this rank
@@ -346,7 +349,6 @@ def main():
                                      lengths=sorted_lens[i][rank * B_local:(rank + 1) * B_local])
         else:
             b = workloads.make_batch(3, B_local, seed_offset=1000 * rank + i)
-        t_local.append(int(b['lengths'].max()))
         parts = []
         if n_micro > 1:        # rows sorted by length (a permutation of the batch), each part padded to its own longest row
             order = np.argsort(-b['lengths'], kind='stable')
@@ -357,6 +359,7 @@ def main():
                 parts.append(tuple(torch.from_numpy(np.ascontiguousarray(b[n][rows, :Tk])).to(dev) for n in ('x', 'mask', 'y')))
         else:
             parts.append(tuple(torch.from_numpy(b[n]).to(dev) for n in ('x', 'mask', 'y')))
+        t_local.append(int(sum(p_[0].shape[1] for p_ in parts)))     # scan steps of this rank's pass(es)
         batches.append((parts, b['frames']))
 
     def step(i):
@@ -367,13 +370,14 @@ def main():
             net.backward()
             ar.finish()
         else:
-            net.world = len(parts)                       # loss scale 1 / (rows of all parts)
+            net.world = len(parts) * world               # loss scale 1 / (rows of all parts on all ranks)
             for k, (x, m, y) in enumerate(parts):
                 net.loss(x, m, y, m)
                 net.backward()
                 net.grad_accumulate(first=(k == 0))
             net.grad_accumulated()
-            net.world = 1
+            ar.reduce_all()
+            net.world = world
         net.adam_update(1e-3)
         return frames
 
