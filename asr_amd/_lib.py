@@ -73,6 +73,9 @@ _SIGS = {
     'asr_gemm_f32_ws': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
     'asr_gemm_bf16_ws': (i32, [i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
     'asr_gemm_bf16x3_ws': (i32, [i32, i32, i32, i32, i32, i32, f32, fp, i32, fp, i32, f32, fp, i32, fp, fp, sz, fp]),
+    'asr_split_ld': (i32, [i32]),
+    'asr_split_bf16x3': (i32, [fp, i32, i32, i32, fp, i32, sz, fp]),
+    'asr_gemm_presplit_ws': (i32, [i32, i32, i32, i32, i32, i32, i32, f32, fp, i32, sz, fp, i32, sz, f32, fp, i32, fp, fp, sz, fp]),
     'asr_swap01': (i32, [fp, fp, i32, i32, i32, i32, i32, fp]),
     'asr_ln_rows_fwd': (i32, [fp, i32, i32, fp, i32, fp, fp, i32, fp, fp, fp, fp, i32, fp]),
     'asr_ln_rows_bwd': (i32, [fp, i32, i32, fp, fp, fp, i32, fp, i32, fp]),

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define SPL_KROW 320                      // bytes per k row of the row-contiguous image: 128 bf16 + 64 B, so that the
@@ -261,14 +262,22 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned* out) {
     }
 }
 
-template <bool TA, bool TB, int TERMS>
+// PA / PB: the operand arrives PRE-SPLIT (asr_split_bf16x3: three bf16 planes of the tensor's own row-major shape,
+// rows padded with zeros to a multiple of 8 columns; `A` / `B` then point at plane 0, lda / ldb count bf16 elements
+// and plA / plB are the plane strides).  Staging such an operand is one 16-byte load and one ds_write_b128 per
+// thread, part and K-tile with no arithmetic (odd tiles flip the sign bits of A's parts), where the on-the-fly split
+// costs ~13 VALU instructions per element pair: a tensor that feeds several products (a layer's input: x.W_x,
+// x.W_xhat and the two weight gradients) is split once.  Products and their order are the same as on the fly:
+// results are bit-identical.
+template <bool TA, bool TB, int TERMS, bool PA = false, bool PB = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K, float alpha,
                                                           const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb,
                                                           float beta, float* __restrict__ C, int ldc,
                                                           const float* __restrict__ bias, int ntn,
-                                                          int kchunk, float* __restrict__ part) {
+                                                          int kchunk, float* __restrict__ part, size_t plA, size_t plB) {
     constexpr int NP = TERMS == 1 ? 1 : 3;
+    static_assert(!(PA || PB) || TERMS == 6, "pre-split operands: the 6-product form only");
     constexpr bool AKM = TA, BKM = !TB;        // operand stored [k][row] (row contiguous)
     __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][NP][SPL_IMG];   // [buf][A|B][part]
 
@@ -293,8 +302,28 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     f32x4 ra[2], rb[2];
-    const bool vecA = ((((uintptr_t)A) & 15) == 0) && ((lda & 3) == 0);
-    const bool vecB = ((((uintptr_t)B) & 15) == 0) && ((ldb & 3) == 0);
+    u32x4s qa[NP], qb[NP];                                 // pre-split operands: 8 bf16 per thread and part
+    const bool vecA = ((((uintptr_t)A) & 15) == 0) && ((lda & (PA ? 7 : 3)) == 0);
+    const bool vecB = ((((uintptr_t)B) & 15) == 0) && ((ldb & (PB ? 7 : 3)) == 0);
+    // pre-split operand, stored [k][row] (kmaj): thread -> k = tid / 16, rows 8 (tid % 16) ..;  stored [row][k]: row =
+    // tid / 2, k = 8 (tid % 2) ..  Columns between the matrix and its padded width hold zeros.
+    auto load_pre = [&](u32x4s* q, const float* X, int ld, size_t pl, bool kmaj, int k0, int r0, int nrows, int kdim,
+                        bool fast) {
+        const unsigned short* P = (const unsigned short*)X;
+        const int rr = kmaj ? k0 + (tid >> 4) : r0 + (tid >> 1);
+        const int cc = kmaj ? r0 + (tid & 15) * 8 : k0 + (tid & 1) * 8;
+        const bool ok = fast || (kmaj ? (rr < kdim && cc < ld) : (rr < nrows && cc < ld && cc < kdim));
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            q[p] = ok ? *(const u32x4s*)(P + (size_t)p * pl + (size_t)rr * ld + cc) : u32x4s{0, 0, 0, 0};
+    };
+    auto store_pre = [&](unsigned char (*img)[SPL_IMG], const u32x4s* q, bool kmaj, bool neg) {
+        const size_t off = kmaj ? (size_t)(tid >> 4) * SPL_KROW + (tid & 15) * 16
+                                : (size_t)(tid & 1) * SPL_KHALF + (tid >> 1) * 16;
+        const unsigned flip = neg ? 0x80008000u : 0u;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *(u32x4s*)(img[p] + off) = q[p] ^ flip;
+    };
     auto ld4 = [&](const float* X, int ld, int r, int c, int R, int Cc, bool vec) -> f32x4 {
         if (vec && r < R && c + 3 < Cc) return *(const f32x4*)(X + (size_t)r * ld + c);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -308,23 +337,35 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
     //                      [row][k] storage: e = 0, 1: row (e * 256 + tid) / 4, 4 k at 4 ((e * 256 + tid) % 4).
     const int kp = tid >> 5, c4 = (tid & 31) * 4;
     auto load_tiles_fast = [&](f32x4* ra, f32x4* rb, int k0) {
+        if (PA) load_pre(qa, A, lda, plA, AKM, k0, m0, M, K, true);
+        if (PB) load_pre(qb, B, ldb, plB, BKM, k0, n0, N, K, true);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = e * 256 + tid;
-            if (AKM) ra[e] = *(const f32x4*)(A + (size_t)(k0 + 2 * kp + e) * lda + m0 + c4);
-            else     ra[e] = *(const f32x4*)(A + (size_t)(m0 + idx / 4) * lda + k0 + (idx % 4) * 4);
-            if (BKM) rb[e] = *(const f32x4*)(B + (size_t)(k0 + 2 * kp + e) * ldb + n0 + c4);
-            else     rb[e] = *(const f32x4*)(B + (size_t)(n0 + idx / 4) * ldb + k0 + (idx % 4) * 4);
+            if (!PA) {
+                if (AKM) ra[e] = *(const f32x4*)(A + (size_t)(k0 + 2 * kp + e) * lda + m0 + c4);
+                else     ra[e] = *(const f32x4*)(A + (size_t)(m0 + idx / 4) * lda + k0 + (idx % 4) * 4);
+            }
+            if (!PB) {
+                if (BKM) rb[e] = *(const f32x4*)(B + (size_t)(k0 + 2 * kp + e) * ldb + n0 + c4);
+                else     rb[e] = *(const f32x4*)(B + (size_t)(n0 + idx / 4) * ldb + k0 + (idx % 4) * 4);
+            }
         }
     };
     auto load_tiles = [&](int k0) {
+        if (PA) load_pre(qa, A, lda, plA, AKM, k0, m0, M, K, false);
+        if (PB) load_pre(qb, B, ldb, plB, BKM, k0, n0, N, K, false);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = e * 256 + tid;
-            if (AKM) ra[e] = ld4(A, lda, k0 + 2 * kp + e, m0 + c4, K, M, vecA);
-            else     ra[e] = ld4(A, lda, m0 + idx / 4, k0 + (idx % 4) * 4, M, K, vecA);
-            if (BKM) rb[e] = ld4(B, ldb, k0 + 2 * kp + e, n0 + c4, K, N, vecB);
-            else     rb[e] = ld4(B, ldb, n0 + idx / 4, k0 + (idx % 4) * 4, N, K, vecB);
+            if (!PA) {
+                if (AKM) ra[e] = ld4(A, lda, k0 + 2 * kp + e, m0 + c4, K, M, vecA);
+                else     ra[e] = ld4(A, lda, m0 + idx / 4, k0 + (idx % 4) * 4, M, K, vecA);
+            }
+            if (!PB) {
+                if (BKM) rb[e] = ld4(B, ldb, k0 + 2 * kp + e, n0 + c4, K, N, vecB);
+                else     rb[e] = ld4(B, ldb, n0 + idx / 4, k0 + (idx % 4) * 4, N, K, vecB);
+            }
         }
     };
     auto store_op = [&](unsigned char (*img)[SPL_IMG], const f32x4* r, bool kmaj, float sg) {
@@ -344,8 +385,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
     // K-tile t enters with the sign (-1)^t on its A operand and is joined with the same sign: see mfma_tile
     auto sgn = [](int t) { return (TERMS > 1 && (t & 1)) ? -1.0f : 1.0f; };
     auto store_tiles = [&](int t) {
-        store_op(sm[t & 1][0], ra, AKM, sgn(t));
-        store_op(sm[t & 1][1], rb, BKM, 1.0f);
+        if (PA) store_pre(sm[t & 1][0], qa, AKM, TERMS > 1 && (t & 1));
+        else store_op(sm[t & 1][0], ra, AKM, sgn(t));
+        if (PB) store_pre(sm[t & 1][1], qb, BKM, false);
+        else store_op(sm[t & 1][1], rb, BKM, 1.0f);
     };
     const int lr = lane & 31, lk = lane >> 5;
     // transposed read: lane 4q + p of a 16-lane group addresses k row q, rows 4p .. 4p + 3 of the group's 16 rows
@@ -508,8 +551,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 // fill the chip and K is long (the weight-gradient contractions, K = T*B).
 static int gemm_launch(int mode, int transA, int transB, int M, int N, int K, float alpha, const float* A,
                        int lda, const float* B, int ldb, float beta, float* C, int ldc,
-                       const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
+                       const float* bias, float* ws, size_t ws_bytes, hipStream_t stream, int preA = 0, int preB = 0,
+                       size_t plA = 0, size_t plB = 0) {
     if (M < 0 || N < 0 || K < 0 || !C) return ASR_ERR_ARG;
+    if ((preA || preB) && mode != 6) return ASR_ERR_ARG;
+    // a pre-split operand: plane 0 and the planes 16-byte aligned, padded rows (asr_split_bf16x3 makes them so)
+    if (preA && ((((uintptr_t)A) & 15) || (lda & 7) || (plA & 7))) return ASR_ERR_ARG;
+    if (preB && ((((uintptr_t)B) & 15) || (ldb & 7) || (plB & 7))) return ASR_ERR_ARG;
     if (M == 0 || N == 0) return ASR_OK;
     if (K > 0 && (!A || !B)) return ASR_ERR_ARG;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
@@ -535,14 +583,17 @@ static int gemm_launch(int mode, int transA, int transB, int M, int N, int K, fl
     }
     float* part = ns > 1 ? ws : nullptr;
     dim3 grid(tiles, ns), block(256);
+#define SPLIT_(TA_, TB_, T_, PA_, PB_)                                                                   \
+    hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, T_, PA_, PB_>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, \
+                       ldb, beta, C, ldc, bias, ntn, kchunk, part, plA, plB)
 #define LAUNCH(TA_, TB_)                                                                                \
     do {                                                                                                \
-        if (mode == 6) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 6>), grid, block, 0, stream, M, N, K, alpha, A, \
-                                     lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);               \
-        else if (mode == 8) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 8>), grid, block, 0, stream, M, N, K, alpha, A, \
-                                     lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);               \
-        else if (mode == 1) hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, 1>), grid, block, 0, stream, M, N, K, alpha, A, \
-                                     lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);               \
+        if (mode == 6 && preA && preB) SPLIT_(TA_, TB_, 6, true, true);                                 \
+        else if (mode == 6 && preA) SPLIT_(TA_, TB_, 6, true, false);                                   \
+        else if (mode == 6 && preB) SPLIT_(TA_, TB_, 6, false, true);                                   \
+        else if (mode == 6) SPLIT_(TA_, TB_, 6, false, false);                                          \
+        else if (mode == 8) SPLIT_(TA_, TB_, 8, false, false);                                          \
+        else if (mode == 1) SPLIT_(TA_, TB_, 1, false, false);                                          \
         else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, block, 0, stream, M, N, K, alpha, A, \
                                 lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);                    \
     } while (0)
@@ -551,6 +602,7 @@ static int gemm_launch(int mode, int transA, int transB, int M, int N, int K, fl
     else if (transA && !transB) LAUNCH(true, false);
     else LAUNCH(true, true);
 #undef LAUNCH
+#undef SPLIT_
     ASR_CHECK_LAUNCH();
     if (ns > 1) {
         const size_t tot = (size_t)M * N;
@@ -582,6 +634,62 @@ extern "C" int asr_gemm_bf16x3_ws(int terms, int transA, int transB, int M, int 
     if (terms != 8 && terms != 6 && terms != 1) return ASR_ERR_ARG;
     return gemm_launch(terms, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws,
                        ws_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 [rows][cols] (leading dimension ldx) -> three bf16 planes [rows][ldp], ldp = cols rounded up to a multiple of 8,
+// the padding columns zero: x = h + m + l with h = rn(x), m = rn(x - h), l = rn(x - h - m) (split_pair above).
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ X, int ldx, int rows, int cols,
+                                                     unsigned short* __restrict__ P, int ldp, size_t pl) {
+    const int g8 = ldp >> 3;
+    const size_t tot = (size_t)rows * g8;
+    const bool vec = ((((uintptr_t)X) & 15) == 0) && ((ldx & 3) == 0);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / g8), c = (int)(i % g8) * 8;
+        float v[8];
+        const float* src = X + (size_t)r * ldx + c;
+        if (vec && c + 7 < cols) {
+            const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = c + k < cols ? src[k] : 0.f;
+        }
+        unsigned w[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) split_pair<3>(v[2 * k], v[2 * k + 1], w[k]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *(u32x4s*)(P + (size_t)p * pl + (size_t)r * ldp + c) = u32x4s{w[0][p], w[1][p], w[2][p], w[3][p]};
+    }
+}
+
+extern "C" int asr_split_ld(int cols) { return (cols + 7) & ~7; }
+
+extern "C" int asr_split_bf16x3(const float* X, int ldx, int rows, int cols, void* planes, int ldp,
+                                size_t plane_stride, hipStream_t stream) {
+    if (rows < 0 || cols < 0 || !planes || ldp < cols || (ldp & 7) || (plane_stride & 7) ||
+        plane_stride < (size_t)rows * ldp || (((uintptr_t)planes) & 15) || (rows && cols && !X))
+        return ASR_ERR_ARG;
+    if (!rows || !cols) return ASR_OK;
+    const size_t tot = (size_t)rows * (ldp >> 3);
+    const int grid = (int)((tot + 255) / 256 < 16384 ? (tot + 255) / 256 : 16384);
+    hipLaunchKernelGGL(split3_kernel, dim3(grid), dim3(256), 0, stream, X, ldx, rows, cols, (unsigned short*)planes,
+                       ldp, plane_stride);
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
+// asr_gemm_bf16x3_ws (6 products) with either operand, or both, given as the planes asr_split_bf16x3 wrote:
+// preA / preB != 0: A / B points at plane 0 of op's STORED matrix (same shape and transposition flags as the fp32
+// form), lda / ldb = ldp, planeA / planeB = plane_stride.  Bit-identical to the fp32-operand call.
+extern "C" int asr_gemm_presplit_ws(int preA, int preB, int transA, int transB, int M, int N, int K, float alpha,
+                                    const void* A, int lda, size_t planeA, const void* B, int ldb, size_t planeB,
+                                    float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_bytes,
+                                    hipStream_t stream) {
+    return gemm_launch(6, transA, transB, M, N, K, alpha, (const float*)A, lda, (const float*)B, ldb, beta, C, ldc,
+                       bias, ws, ws_bytes, stream, preA, preB, planeA, planeB);
 }
 
 extern "C" int asr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A,

@@ -36,9 +36,59 @@ PRECISION = DEFAULT_PRECISION
 SPLIT_MIN_WORK = 1 << 24
 
 
+class Split3(object):
+    """An fp32 matrix held as its three bf16 parts (asr_split_bf16x3): planes[p] is (rows, ld) bf16 with the matrix in
+    the first `cols` columns.  Behaves like the 2-D tensor it stands for where gemm() needs it: shape, row slices,
+    column slices at multiples of 8.  Made by split3(); passed to gemm() in place of the tensor."""
+    def __init__(self, planes, r0, r1, c0, c1):
+        self.planes = planes                     # (3, R, ld) int16 storage
+        self.r0, self.r1, self.c0, self.c1 = r0, r1, c0, c1
+        self.shape = (r1 - r0, c1 - c0)
+
+    @property
+    def ld(self):
+        return self.planes.shape[2]
+
+    @property
+    def plane_stride(self):
+        return self.planes.stride(0)
+
+    def ptr(self):
+        return self.planes.data_ptr() + 2 * (self.r0 * self.ld + self.c0)
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key, slice(None))
+        rs, cs = key
+        nr, ncol = self.shape
+        a, b, st = rs.indices(nr)
+        c, d, st2 = cs.indices(ncol)
+        assert st == 1 and st2 == 1 and c % 8 == 0, 'Split3: unit-stride slices, columns from a multiple of 8'
+        return Split3(self.planes, self.r0 + a, self.r0 + b, self.c0 + c, self.c0 + d)
+
+
+def split3(X, out=None):
+    """The three bf16 parts of the 2-D fp32 view X, once, for every product that reads it."""
+    _chk2d(X)
+    R, Cc = X.shape
+    L = _lib.lib()
+    ld = L.asr_split_ld(Cc)
+    if out is None or out.numel() < 3 * R * ld:
+        out = torch.empty(3 * R * ld, dtype=torch.int16, device=X.device)
+    planes = out[:3 * R * ld].view(3, R, ld)
+    check(L.asr_split_bf16x3(_p(X), max(X.stride(0), 1), R, Cc, _p(planes), ld, R * ld, _s()), 'asr_split_bf16x3')
+    return Split3(planes, 0, R, 0, Cc)
+
+
 def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
-    """Cm = alpha*op(A)*op(B) + beta*Cm (+bias).  2-D float32 views with unit inner stride."""
-    _chk2d(A); _chk2d(B); _chk2d(Cm)
+    """Cm = alpha*op(A)*op(B) + beta*Cm (+bias).  2-D float32 views with unit inner stride; A and / or B may be a
+    Split3 (pre-split operand) when the product runs in the default precision."""
+    pa, pb = isinstance(A, Split3), isinstance(B, Split3)
+    if not pa:
+        _chk2d(A)
+    if not pb:
+        _chk2d(B)
+    _chk2d(Cm)
     M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
     K2, N = (B.shape[1], B.shape[0]) if tb else (B.shape[0], B.shape[1])
     assert K == K2 and tuple(Cm.shape) == (M, N), (A.shape, B.shape, Cm.shape, ta, tb)
@@ -48,6 +98,15 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
         ws = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=Cm.device)     # split-K partials
         _gemm_ws[key] = ws
     L = _lib.lib()
+    if pa or pb:
+        assert PRECISION == 'f32x3', 'pre-split operands belong to the default precision'
+        check(L.asr_gemm_presplit_ws(int(pa), int(pb), int(ta), int(tb), M, N, K, alpha,
+                                     A.ptr() if pa else _p(A), A.ld if pa else max(A.stride(0), 1),
+                                     A.plane_stride if pa else 0,
+                                     B.ptr() if pb else _p(B), B.ld if pb else max(B.stride(0), 1),
+                                     B.plane_stride if pb else 0, beta, _p(Cm), max(Cm.stride(0), 1), _p(bias),
+                                     _p(ws), ws.numel() * 4, _s()), 'asr_gemm_presplit_ws')
+        return Cm
     terms = GEMM_TERMS[PRECISION] if M * N * K >= SPLIT_MIN_WORK else 0
     args = (int(ta), int(tb), M, N, K, alpha, _p(A), max(A.stride(0), 1), _p(B), max(B.stride(0), 1), beta,
             _p(Cm), max(Cm.stride(0), 1), _p(bias), _p(ws), ws.numel() * 4, _s())

@@ -56,6 +56,21 @@ int asr_gemm_bf16x3_ws(int terms, int transA, int transB, int M, int N, int K, f
                        const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
                        size_t ws_bytes, asr_stream_t stream);
 
+/* The same products with operands split ONCE per tensor instead of once per product: asr_split_bf16x3 writes the
+ * three bf16 parts of an fp32 matrix (rows x cols, leading dimension ldx) as planes of the matrix's own row-major
+ * shape, leading dimension ldp = asr_split_ld(cols) (cols rounded up to 8, padding zeroed), `plane_stride` elements
+ * apart (>= rows * ldp, a multiple of 8; `planes` 16-byte aligned).  asr_gemm_presplit_ws is asr_gemm_bf16x3_ws with
+ * terms = 6 whose A and / or B (preA / preB != 0) is such a set of planes: the pointer is plane 0 of the stored matrix
+ * (sub-matrices: offset by whole rows, or by a multiple of 8 columns), lda / ldb = ldp.  Bit-identical to the
+ * fp32-operand call; a layer input feeds four T.dot's (x.W_x, x.W_xhat and their weight gradients,
+ * libs/lasagne_libs/hyper_lhuc_layers.py:469,216-224 and theano.grad of them). */
+int asr_split_ld(int cols);
+int asr_split_bf16x3(const float* X, int ldx, int rows, int cols, void* planes, int ldp, size_t plane_stride,
+                     asr_stream_t stream);
+int asr_gemm_presplit_ws(int preA, int preB, int transA, int transB, int M, int N, int K, float alpha, const void* A,
+                         int lda, size_t planeA, const void* B, int ldb, size_t planeB, float beta, float* C, int ldc,
+                         const float* bias, float* ws, size_t ws_bytes, asr_stream_t stream);
+
 /* dst[b][a][:] = src[a][b][:]  -- input.dimshuffle(1,0,2), libs/lhuclstm_layers.py:181,213 */
 int asr_swap01(const float* src, float* dst, int A, int B, int D, int ld_src, int ld_dst,
                asr_stream_t stream);

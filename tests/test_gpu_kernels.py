@@ -303,3 +303,44 @@ def test_activation_accuracy(kind, name):
             f.write(json.dumps(dict(fn=name, max_ulp=worst, at=worst_x, arguments=(1 << 32) // step)) + '\n')
     print('%s: max error %.2f ulp at x = %r' % (name, worst, worst_x))
     assert worst <= 3.5, (name, worst, worst_x)
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_presplit_bit_identical(ta, tb):
+    """asr_gemm_presplit_ws (operands split once by asr_split_bf16x3) gives the bits of asr_gemm_bf16x3_ws with 6
+    products for either or both operands pre-split: interior and edge tiles, K tails, widths that are not multiples of
+    8, split-K, alpha / beta / bias, and sub-matrices taken by rows and by columns (a multiple of 8) of the planes."""
+    from asr_amd import _lib, ops
+    L = _lib.lib()
+    rng = np.random.default_rng(31 + 2 * ta + tb)
+    ws = torch.empty(16 << 20, device='cuda')
+    s = torch.cuda.current_stream().cuda_stream
+    for M, N, K in ((128, 128, 64), (256, 384, 160), (200, 136, 50), (37, 300, 1003), (256, 128, 8192), (5, 7, 3),
+                    (1000, 515, 123)):
+        sa, sb = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
+        # operands live inside larger matrices: 3 extra rows on top, 8 extra columns on the left
+        Af = torch.from_numpy((rng.standard_normal((sa[0] + 3, sa[1] + 8)) * np.exp(rng.standard_normal((sa[0] + 3, sa[1] + 8)))).astype(np.float32)).cuda()
+        Bf = torch.from_numpy(rng.standard_normal((sb[0] + 3, sb[1] + 8)).astype(np.float32)).cuda()
+        A, B = Af[3:, 8:], Bf[3:, 8:]
+        As, Bs = ops.split3(Af)[3:, 8:], ops.split3(Bf)[3:, 8:]
+        C0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda()
+        bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
+        want = C0.clone()
+        rc = L.asr_gemm_bf16x3_ws(6, ta, tb, M, N, K, 0.5, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), 1.0,
+                                  want.data_ptr(), N, bias.data_ptr(), ws.data_ptr(), ws.numel() * 4, s)
+        assert rc == 0
+        for pa, pb in ((1, 1), (1, 0), (0, 1)):
+            got = C0.clone()
+            rc = L.asr_gemm_presplit_ws(pa, pb, ta, tb, M, N, K, 0.5,
+                                        As.ptr() if pa else A.data_ptr(), As.ld if pa else A.stride(0), As.plane_stride if pa else 0,
+                                        Bs.ptr() if pb else B.data_ptr(), Bs.ld if pb else B.stride(0), Bs.plane_stride if pb else 0,
+                                        1.0, got.data_ptr(), N, bias.data_ptr(), ws.data_ptr(), ws.numel() * 4, s)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (M, N, K, pa, pb, (got - want).abs().max().item())
+    # the parts add up to the value: h + m + l == x wherever x is a normal float
+    X = torch.from_numpy((rng.standard_normal((50, 37)) * np.exp(3 * rng.standard_normal((50, 37)))).astype(np.float32)).cuda()
+    sp = ops.split3(X)
+    parts = (sp.planes.view(torch.int16).to(torch.int32) << 16).view(torch.float32)[:, :, :37].cpu().numpy().astype(np.float64)
+    assert sp.ld == 40 and (sp.planes[:, :, 37:] == 0).all()
+    assert np.max(np.abs(parts.sum(0) - X.cpu().numpy()) / np.abs(X.cpu().numpy())) < 2.0 ** -22
