@@ -227,6 +227,28 @@ def eval_net(predict_fn, data_stream, use_ivectors=False, delay=0):
     return tally.result()
 
 
+def eval_net_skip(predict_fn, data_stream, skip, skip_random, use_ivectors=False):
+    """Frame-skipped evaluation (libs/comp_graph_utils.py:200-236): the network sees every `skip`-th frame of every
+    source (transformers.skip_frames: a fixed phase, or a random frame of each group of `skip`), CE per frame is taken
+    over the frames it saw, and the frame error rate over ALL frames of the utterance with each prediction repeated
+    `skip` times (numpy.repeat, cut to the utterance length).  (The reference indexes the repeated (B, T) prediction
+    with three subscripts, :222, which numpy refuses; the two-subscript cut it means is what runs here, as in
+    bin/forward_lstm2.py:96-102.)"""
+    from .transformers import skip_frames, unskip
+    ce_sum = ce_frames = hits = frames = 0.0
+    for batch in data_stream.get_epoch_iterator():
+        x, xm, iv, ivm, y, ym = [np.asarray(a) for a in batch]
+        sx, sxm, siv, _, sy, sym = [np.asarray(a) for a in skip_frames((x, xm, iv, ivm, y, ym), skip, skip_random)]
+        inputs = (sx, sxm, siv, sy, sym) if use_ivectors else (sx, sxm, sy, sym)
+        ce, pred = predict_fn(*inputs)
+        pred = unskip(np.asarray(pred), skip, y.shape[1])
+        ce_sum += float(ce)
+        ce_frames += float(sym.sum())
+        hits += float(((y == pred) * ym).sum())
+        frames += float(ym.sum())
+    return ce_sum / ce_frames, 1.0 - hits / frames
+
+
 def eval_net_tbptt(predict_fn, data_stream, tbptt_layers, num_tbptt_steps, batch_size, right_context,
                    use_ivectors=False, delay=0):
     """The windowed form: state reset per batch, one predict call per window (first one flagged), the

@@ -696,15 +696,26 @@ class Network(object):
         self.dropout_step = 0
         self._drop_ids = []
 
-    def set_precision(self, precision):
+    def set_precision(self, precision, allow_unbounded=False):
         """How the large GEMMs (input projections, output layer, dX, weight-gradient contractions) multiply; the
         recurrences, layer norms, softmax and the optimiser are fp32 in every mode.  Process-wide (asr_amd.ops).
           'f32x3' (default) fp32-grade products on the bf16 matrix cores from operands split into three bf16 parts;
           'f32'   fp32 MFMA throughout;
           'bf16'  the optional mode of BASELINE.json's north_star: operands rounded to bf16, fp32 accumulate,
-                  with the measured bound of tests/test_gpu_bf16.py."""
+                  with the measured bound of tests/test_gpu_bf16.py.  REFUSED for networks with layer norm inside
+                  the recurrence (LN-LSTM(P), cond-LN, ProjectionHyper, the scaling layer's layer-norm option): no
+                  bound can be stated there -- measured on cfg2, |d log p| up to 0.59 and a gradient error of 0.93
+                  of the gradient's norm (the LN stack amplifies even fp32 rounding to 1e-3) -- so the mode raises
+                  instead of silently training on noise; allow_unbounded=True overrides (measurements only)."""
         if precision not in ops.GEMM_TERMS:
             raise ValueError('precision must be one of %s' % sorted(ops.GEMM_TERMS))
+        if precision == 'bf16' and not allow_unbounded:
+            ln = [p.idx for p in self.pairs if getattr(p, 'ln_kind', 0) or getattr(p, 'cell_ln', 0) or
+                  getattr(p, 'ln', False) is True or getattr(p, 'kind', '') == 'prjhyper']
+            if ln:
+                raise _lib.AsrError('set_precision(\'bf16\'): layers %s normalise inside the recurrence; the bf16 mode has '
+                                    'no stated bound for such stacks (tests/test_gpu_bf16.py) and is refused -- use '
+                                    'the default f32x3' % ln)
         ops.PRECISION = precision
         self.precision = precision
 

@@ -572,3 +572,34 @@ def test_regularizable_ranges_cover_the_rec_family():
         assert rr and all(lo % 4 == 0 and hi > lo for lo, hi in rr)
         tot = sum(hi - lo for lo, hi in rr)
         assert 0 < tot < net.store.size
+
+
+def test_eval_net_skip_scores_all_frames_with_repeated_predictions():
+    """libs/comp_graph_utils.py:200-236: CE over the frames the network saw, FER over every frame with the
+    predictions repeated `skip` times; checked against a direct count on a hand-made stream."""
+    from asr_amd import comp_graph_utils as CG
+    rng = np.random.default_rng(3)
+    B, T, D, C, skip = 3, 11, 2, 4, 3
+    lens = np.array([11, 4, 7])
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    m = (np.arange(T)[None] < lens[:, None]).astype(np.float32)
+    y = rng.integers(0, C, (B, T)).astype(np.int32)
+
+    class Stream(object):
+        def get_epoch_iterator(self):
+            yield (x, m, x, m, y, m)
+
+    seen = {}
+
+    def predict_fn(sx, sm, sy, sym):
+        seen['shape'] = sx.shape
+        assert np.array_equal(sx, x[:, ::skip]) and np.array_equal(sy, y[:, ::skip])
+        pred = np.where(np.arange(sx.shape[1])[None] % 2 == 0, sy, (sy + 1) % C)     # right on even skipped frames
+        return 2.5 * sym.sum(), pred
+
+    ce, fer = CG.eval_net_skip(predict_fn, Stream(), skip, False)
+    assert seen['shape'] == (B, 4, D)
+    assert abs(ce - 2.5) < 1e-12
+    pred_full = np.repeat(np.where(np.arange(4)[None] % 2 == 0, y[:, ::skip], (y[:, ::skip] + 1) % C), skip, axis=1)[:, :T]
+    want = 1.0 - ((pred_full == y) * m).sum() / m.sum()
+    assert abs(fer - want) < 1e-12
