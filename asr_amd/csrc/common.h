@@ -8,7 +8,7 @@
 #define ASR_ERR_LAUNCH (-2)     // HIP launch error
 #define ASR_ERR_WS (-3)         // workspace too small
 #define ASR_ERR_TIMEOUT (-4)    // an in-kernel group wait gave up (reported by asr_scan_status)
-#define ASR_ERR_LIMIT (-5)      // problem larger than a fixed built-in buffer (asr_colreduce_static)
+#define ASR_ERR_LIMIT (-5)      // larger than a fixed capacity (asr_colreduce_static's buffer; a scan's resident weights / grid)
 
 #define ASR_CHECK_LAUNCH()                              \
     do {                                                \

@@ -322,9 +322,16 @@ static __device__ __align__(256) float cr_static_scratch[(size_t)CR_SPLIT * CR_S
 static float* cr_static_ptr[CR_MAX_DEVICES];
 static std::mutex cr_static_mu;
 
-static int cr_static_lookup(float** out) {
+static int cr_static_lookup(float** out, hipStream_t stream) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CR_MAX_DEVICES) return ASR_ERR_LAUNCH;
+    // every GPU holds its own copy of the array: a stream of another device must not get this device's address
+    if (stream) {
+        int sdev = -1;
+        if (hipStreamGetDevice(stream, &sdev) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (sdev != dev) return ASR_ERR_ARG;
+    }
+    if (cr_static_ptr[dev]) { *out = cr_static_ptr[dev]; return ASR_OK; }    // resolved before: no lock, no HIP call
     std::lock_guard<std::mutex> lk(cr_static_mu);
     if (!cr_static_ptr[dev]) {
         void* p = nullptr;
@@ -337,11 +344,12 @@ static int cr_static_lookup(float** out) {
 
 extern "C" int asr_colreduce_static(const float* x, int ldx, const float* y, int ldy, int rows, int n, int gmod,
                                     float* out, int accumulate, hipStream_t stream) {
-    if (rows < 0 || n <= 0 || gmod <= 0 || !x || !out) return ASR_ERR_ARG;
+    if (rows < 0 || n <= 0 || gmod <= 0 || (!x && rows != 0) || (!out && x)) return ASR_ERR_ARG;
     if ((size_t)gmod * (size_t)n > CR_STATIC_MAX) return ASR_ERR_LIMIT;
     float* ws = nullptr;
-    const int rc = cr_static_lookup(&ws);
+    const int rc = cr_static_lookup(&ws, stream);
     if (rc != ASR_OK) return rc;
+    if (rows == 0 && !x) return ASR_OK;              // the warm-up form (see the header): address resolved, nothing launched
     dim3 g1((n + 63) / 64, CR_SPLIT, gmod);
     hipLaunchKernelGGL(colreduce1_kernel, g1, dim3(64), 0, stream, x, ldx, y, ldy, rows, n, gmod, ws);
     ASR_CHECK_LAUNCH();

@@ -987,7 +987,7 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
         if (!backward && A.s0 > 0 && (!D.cst || !D.hcst)) return ASR_ERR_ARG;
         if (backward && (A.s0 > 0 || A.s1 < d->T) && !D.carry) return ASR_ERR_ARG;
     }
-    if (A.G * d->ndir > 256) return ASR_ERR_ARG;         // co-residency bound of the persistent grid
+    if (A.G * d->ndir > 256) return ASR_ERR_LIMIT;       // co-residency bound of the persistent grid
     A.T = d->T; A.B = d->B; A.ndir = d->ndir; A.clip = d->grad_clip;
     A.clip_out = d->clip_outcell ? d->grad_clip : 0.f;
     if (d->lhuc_reparam < 0 || d->lhuc_reparam > 4) return ASR_ERR_ARG;
@@ -999,7 +999,7 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
     auto lds_of = [&](int nc) -> size_t {
         return !backward ? (per_wg + (size_t)nc * 3 * 4 * 256) * 4 + 64 : (per_wg + (size_t)nc * HYPER_BWD_STAGE) * 4 + 64;
     };
-    if (lds_of(1) > 160 * 1024) return ASR_ERR_ARG;
+    if (lds_of(1) > 160 * 1024) return ASR_ERR_LIMIT;
     // Knobs, read once per process (experiments only): ASR_SCAN_RPC = 8 cuts the batch into 8-row chunks (two
     // independent recurrences sharing a CU: measured SLOWER, 482 vs 325 ms/step on cfg3, the exchange is bound by
     // memory-side traffic, which doubles); ASR_SCAN_NC / asr_scan_set_chunks_per_wg cap the chunks per workgroup (1, 2 or 4).
@@ -1044,7 +1044,7 @@ static int hyper_launch(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes,
         if ((size_t)per_z * nz <= 256 && lds < 82 * 1024) lds = 82 * 1024;
         A.chunk0 = c0;
         dim3 grid(A.G, d->ndir, nz), block(256 * nc);
-        if (!scan_grid_fits((size_t)per_z * nz, lds)) return ASR_ERR_ARG;
+        if (!scan_grid_fits((size_t)per_z * nz, lds)) return ASR_ERR_LIMIT;
         const void* fn;
         if (!backward) fn = nc == 2 ? (const void*)hyper_scan_fwd_kernel<2> : (const void*)hyper_scan_fwd_kernel<1>;
         else fn = nc == 2 ? (const void*)hyper_scan_bwd_kernel<2> : (const void*)hyper_scan_bwd_kernel<1>;

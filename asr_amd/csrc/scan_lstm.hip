@@ -1290,7 +1290,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     } else {
         cpl = 1;
         UT = pick_ut(d->N, d->ndir);
-        if (!UT) return ASR_ERR_ARG;     // N too large for a co-resident grid
+        if (!UT) return ASR_ERR_LIMIT;   // N too large for a co-resident grid
     }
     A.UT = UT; A.G = d->N / (4 * UT);
 
@@ -1319,7 +1319,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
         if (backward) return ((size_t)UT * A.KT * 256 + (size_t)nc * UT * 1280) * 4 + 64;
         return ((size_t)UT * A.KSP * 64 + (size_t)nc * UT * 1024) * 4 + 64 + (fused_cln ? 1024 * nc : 0);
     };
-    if (lds_of(1) > 160 * 1024) return ASR_ERR_ARG;
+    if (lds_of(1) > 160 * 1024) return ASR_ERR_LIMIT;    // the resident weights do not fit a CU's LDS
     const int nc_cap = scan_nc_cap() >= 2 ? 2 : 1;
 
     for (int c0 = 0; c0 < nchunk_total;) {
@@ -1337,7 +1337,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
         Al.nchunk = nz * nc;
         Al.chunk0 = c0;
         dim3 grid(A.G, d->ndir, nz), block(256 * nc);
-        if (!scan_grid_fits((size_t)A.G * d->ndir * nz, lds)) return ASR_ERR_ARG;
+        if (!scan_grid_fits((size_t)A.G * d->ndir * nz, lds)) return ASR_ERR_LIMIT;
         const void* fn = nullptr;
 #define PICK_NC_(...) (nc == 2 ? (const void*)__VA_ARGS__, 2> : (const void*)__VA_ARGS__, 1>)
         if (!backward) {

@@ -913,6 +913,8 @@ class Network(object):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         r = call()
+        if r != 0:                  # a refused launch (the caller may retry per direction): nothing to time
+            return r
         e1.record()
         steps = (getattr(desc, 'step1', 0) or desc.T) - getattr(desc, 'step0', 0)
         self.scan_events.append((kind, bool(backward), steps * desc.B, desc.ndir, e0, e1))
@@ -927,7 +929,7 @@ class Network(object):
         fn = L.asr_lstm_scan_bwd if backward else L.asr_lstm_scan_fwd
         rc = self._timed('lstm', backward, desc, lambda: fn(C.byref(desc), ws.data_ptr(), ws.numel(),
                                                             torch.cuda.current_stream().cuda_stream))
-        if rc == -1 and desc.ndir == 2:
+        if rc == -5 and desc.ndir == 2:        # ASR_ERR_LIMIT
             # the library refuses a grid or an LDS share that cannot be co-resident before it launches anything; the two
             # directions of a layer are independent, so a layer too wide for one launch gets one launch per direction
             for d in range(2):
@@ -937,8 +939,8 @@ class Network(object):
                 one.dir[0] = desc.dir[d]
                 self.scan_lstm(pair, one, backward, key=('lstm', pair.idx, backward, d))
             return
-        if rc == -1:
-            raise _lib.AsrError('%s failed: ASR_ERR_ARG (-1); if the arguments are in order, %d units are more than the '
+        if rc == -5:
+            raise _lib.AsrError('%s failed: ASR_ERR_LIMIT (-5): %d units are more than the '
                                 'resident-weight scan holds (16*UT*N*4 bytes of LDS per workgroup, UT in {1,2,4}, at most '
                                 '256 workgroups of N/(4*UT) per direction: about 1024 units)' % (what, desc.N))
         check(rc, what)

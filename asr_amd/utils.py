@@ -32,14 +32,29 @@ EvalRecord = namedtuple('EvalRecord', ['train_ce_frame', 'valid_ce_frame', 'vali
 
 # ------------------------------------------------------------------------------------------------
 # restricted unpickling
+def _np_core(sub):
+    """numpy's core sub-module under the name this numpy has (numpy._core from 2.0 on, numpy.core before)."""
+    import importlib
+    try:
+        return importlib.import_module('numpy._core.' + sub)
+    except ImportError:
+        return importlib.import_module('numpy.core.' + sub)
+
+
+def _latin1_bytes(text, encoding):
+    """What protocol-2 pickles of Python-3 bytes objects call: codecs.encode(str, 'latin1').  Only that form is
+    accepted (the encoding name of a general codecs.encode drives a codec lookup that imports modules)."""
+    if not isinstance(text, str) or encoding not in ('latin1', 'latin-1'):
+        raise pickle.UnpicklingError('asr_amd refuses codecs.encode(%s, %r)' % (type(text).__name__, encoding))
+    return text.encode('latin1')
+
+
 def _numpy_global(module, name):
     mod = module.replace('numpy.core', 'numpy._core')      # numpy < 2 wrote numpy.core.*
     if mod == 'numpy._core.multiarray' and name in ('_reconstruct', 'scalar'):
-        import numpy._core.multiarray as m
-        return getattr(m, name)
+        return getattr(_np_core('multiarray'), name)
     if mod == 'numpy._core.numeric' and name == '_frombuffer':
-        import numpy._core.numeric as m
-        return m._frombuffer
+        return _np_core('numeric')._frombuffer
     if mod == 'numpy' and name in ('ndarray', 'dtype'):
         return getattr(np, name)
     return None
@@ -55,11 +70,10 @@ class _DataUnpickler(pickle.Unpickler):
             return g
         if (module, name) == ('collections', 'OrderedDict'):
             return OrderedDict
-        if name == 'EvalRecord':
-            return EvalRecord
+        if name == 'EvalRecord' and module in ('asr_amd.utils', 'libs.utils', 'utils', '__main__'):
+            return EvalRecord                   # this module's, or the reference's libs/utils.py:87-89 namedtuple
         if (module, name) in (('_codecs', 'encode'), ('codecs', 'encode')):
-            import codecs                       # protocol-2 bytes objects written by Python 3
-            return codecs.encode
+            return _latin1_bytes                # protocol-2 bytes objects written by Python 3
         raise pickle.UnpicklingError('asr_amd refuses to unpickle %s.%s: model and history files hold '
                                      'numpy arrays and plain containers only' % (module, name))
 

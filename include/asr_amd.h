@@ -27,7 +27,8 @@ typedef struct ihipStream_t* asr_stream_t; /* hipStream_t */
 #define ASR_ERR_LAUNCH (-2)
 #define ASR_ERR_WS (-3)
 #define ASR_ERR_TIMEOUT (-4)
-#define ASR_ERR_LIMIT (-5)   /* larger than a fixed built-in buffer (asr_colreduce_static) */
+#define ASR_ERR_LIMIT (-5)   /* larger than a fixed capacity: asr_colreduce_static's built-in buffer; a layer whose
+                              * resident weights / persistent grid do not fit the chip (asr_*_scan_*) */
 
 /* K1.  C = alpha*op(A)*op(B) + beta*C (+bias[N] per row); exact-fp32 MFMA.  Replaces every T.dot on
  * the path: input projection libs/lhuclstm_layers.py:189, libs/lasagne_libs/recurrent_layers.py:701,
@@ -94,7 +95,10 @@ int asr_colreduce(const float* x, int ldx, const float* y, int ldy, int rows, in
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The stage-1
  * partials live in a 4 MiB device array built into the library (one copy per GPU, held until the process
  * ends), so gmod * n <= 32768 or ASR_ERR_LIMIT.  The call allocates nothing; `stream` must belong to the
- * current device.  All calls on one GPU share that array: calls that overlap on one GPU race. */
+ * current device (ASR_ERR_ARG otherwise: every GPU has its own copy of the array).  All calls on one GPU share that
+ * array: calls that overlap on one GPU race.  The first call on a device resolves the array's address
+ * (hipGetSymbolAddress, under a lock): make it outside graph capture, e.g. the warm-up form x = NULL, rows = 0
+ * (n = gmod = 1), which resolves the address and launches nothing. */
 int asr_colreduce_static(const float* x, int ldx, const float* y, int ldy, int rows, int n, int gmod,
                          float* out, int accumulate, asr_stream_t stream);
 

@@ -202,6 +202,20 @@ def test_model_pickle_refuses_code(tmp_path):
             pickle.dump([vals, None, np.int64(4)], f, protocol=proto)
         got, upd, epoch = utils.load_network_pickle(p)
         assert upd is None and int(epoch) == 4 and all(np.array_equal(a, b) for a, b in zip(got, vals))
+    # codecs.encode is only the latin1 form Python 3 writes for bytes; EvalRecord only from the modules that define it
+    class Enc(object):
+        def __reduce__(self):
+            import codecs
+            return (codecs.encode, ('x', 'idna'))
+
+    with open(p, 'wb') as f:
+        pickle.dump(Enc(), f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError, match='refuses'):
+        utils.load_network_pickle(p)
+    with open(p, 'wb') as f:
+        f.write(b'\x80\x02cos\nEvalRecord\nq\x00.')       # GLOBAL os.EvalRecord
+    with pytest.raises(pickle.UnpicklingError, match='refuses'):
+        utils.EvalHistory.load(p)
     h = utils.EvalHistory()
     assert h.add(1.0, (2.0, 0.5), (2.1, 0.6)) and not h.add(1.0, (2.0, 0.7), (2.1, 0.6))
     h.save(p)

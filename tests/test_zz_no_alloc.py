@@ -47,3 +47,14 @@ def test_static_scratch_colreduce_rejects_oversize():
     assert L.asr_colreduce_static(x.data_ptr(), 32772, None, 0, 4, 32772, 1, out.data_ptr(), 0, st) == -5
     assert L.asr_colreduce_static(x.data_ptr(), 2049, None, 0, 4, 2049, 16, out.data_ptr(), 0, st) == -5
     assert L.asr_colreduce_static(None, 4, None, 0, 4, 4, 1, out.data_ptr(), 0, st) == -1
+
+
+def test_static_scratch_warm_up_form_launches_nothing():
+    """x = NULL, rows = 0: resolves the array's address for the current device (to be done once outside graph
+    capture) and returns ASR_OK without touching `out`."""
+    L = _lib.lib()
+    out = torch.full((8,), 3.0, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.asr_colreduce_static(None, 0, None, 0, 0, 1, 1, None, 0, st) == 0
+    torch.cuda.synchronize()
+    assert (out == 3.0).all()
