@@ -118,13 +118,19 @@ def _all_grad_errs(got, want, names):
                    for k, (n, g, og) in enumerate(zip(names, got, want))), reverse=True)
 
 
-@pytest.mark.timeout(1100)
-def test_cfg3_full_length_vs_oracle():
+def _cfg3_setup():
     net, _ = build_cfg(3)
     vals = perturb_params(net, 60, 0.02)
     b = workloads.make_batch(3, 16, seed_offset=0)
+    assert b['mask'].shape[1] > 2000
+    return net, vals, b
+
+
+@pytest.mark.timeout(900)
+def test_cfg3_full_length_end_to_end_vs_oracle():
+    """Free-running through 4 layers x 2262 steps: posteriors, log-posteriors, loss, argmax, every gradient."""
+    net, vals, b = _cfg3_setup()
     B, T = b['mask'].shape
-    assert T > 2000
     x, m, y = _t(b['x']), _t(b['mask']), _t(b['y'])
     post = net.posteriors(x, m).cpu().numpy()
     net.check_status()
@@ -138,6 +144,7 @@ def test_cfg3_full_length_vs_oracle():
     _, os_, opred, ograds = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
     opost = np.exp(O.log_softmax(onet.logits))
     secs = time.time() - t0
+    del onet
     valid = b['mask'][:, :, None] > 0
     ef = relerr(post * valid, opost * valid)
     lp, olp = np.log(post[valid[:, :, 0]]), np.log(opost[valid[:, :, 0]])
@@ -146,10 +153,36 @@ def test_cfg3_full_length_vs_oracle():
     top = []
     eg, gname = _grad_errs(grads, ograds, names, top)
     agree = float(((pred.cpu().numpy() == opred) | (b['mask'] == 0)).mean())
-    # kernel parity, one layer at a time on the oracle's own layer inputs (fixed bounds)
+    # what float32 arithmetic itself loses on this network (same restatement, numpy float32)
+    o32 = O.OracleNetwork(net.describe(), vals, dtype=np.float32)
+    _, _, _, g32 = o32.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    p32 = np.exp(O.log_softmax(o32.logits.astype(np.float64)))
+    floor_f = relerr(p32 * valid, opost * valid)
+    floor_g, _ = _grad_errs(g32, ograds, names)
+    _record(cfg=3, T=int(T), B=16, frames=int(b['frames']), posteriors_rel=ef, logpost_rel=elp, ce_rel=ece,
+            worst_grad_rel=eg, worst_grad=gname, argmax_agree=agree, fixed_bound_f=TOL_F, fixed_bound_g=TOL_G,
+            fp32_floor_posteriors=floor_f, fp32_floor_grad=floor_g, oracle_seconds=secs,
+            mode='end to end free-running at full length; per_layer = each layer on the oracle input of that layer')
+    print('cfg3 T=%d end to end: posteriors %.2e (fp32 floor %.2e), log-posteriors %.2e, CE %.2e, worst gradient '
+          '%.2e (%s; fp32 floor %.2e), oracle %.0f s' % (T, ef, floor_f, elp, ece, eg, gname, floor_g, secs))
+    print('worst gradients:', top)
+    assert ece < TOL_F and elp < TOL_F
+    assert _within(ef, floor_f, TOL_F), (ef, floor_f)
+    assert _within(eg, floor_g, TOL_G), (gname, eg, floor_g)
+    assert agree > 0.9999
+
+
+@pytest.mark.timeout(900)
+def test_cfg3_full_length_each_layer_vs_oracle():
+    """Kernel parity, one layer at a time on the float64 oracle's own input of that layer, T = 2262 steps of the
+    persistent scan in one launch, next to the float32 twin of the oracle on the same input (the floor)."""
+    net, vals, b = _cfg3_setup()
+    T = b['mask'].shape[1]
+    onet = O.OracleNetwork(net.describe(), vals)
+    onet.forward(b['x'], b['mask'])
+    o32 = O.OracleNetwork(net.describe(), vals, dtype=np.float32)
     rng = np.random.default_rng(77)
     per_layer = []
-    o32 = O.OracleNetwork(net.describe(), vals, dtype=np.float32)
     for l, (pair, opair, o32pair) in enumerate(zip(net.pairs, onet.layers, o32.layers)):
         r = _layer_case(net, pair, opair, onet.acts[l], b['mask'], None, onet.acts[l + 1], rng, o32pair=o32pair)
         r['layer'] = l
@@ -157,28 +190,12 @@ def test_cfg3_full_length_vs_oracle():
         print('cfg3 layer %d alone, T=%d: output %.2e (float32 oracle %.2e), worst gradient %.2e (%s; float32 oracle '
               '%.2e)' % (l, T, r['forward_rel'], r['forward_floor_f32'], r['worst_grad_rel'], r['worst_grad'],
                          r['worst_grad_floor_f32']))
-    # what float32 arithmetic itself loses on this network (same restatement, numpy float32)
-    del onet
-    _, _, _, g32 = o32.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
-    p32 = np.exp(O.log_softmax(o32.logits.astype(np.float64)))
-    floor_f = relerr(p32 * valid, opost * valid)
-    floor_g, _ = _grad_errs(g32, ograds, names)
-    _record(cfg=3, T=int(T), B=16, frames=int(b['frames']), posteriors_rel=ef, logpost_rel=elp, ce_rel=ece,
-            worst_grad_rel=eg, worst_grad=gname, argmax_agree=agree, fixed_bound_f=TOL_F, fixed_bound_g=TOL_G,
-            fp32_floor_posteriors=floor_f, fp32_floor_grad=floor_g, per_layer=per_layer, oracle_seconds=secs,
-            mode='end to end free-running at full length; per_layer = each layer on the oracle input of that layer')
-    print('cfg3 T=%d end to end: posteriors %.2e (fp32 floor %.2e), log-posteriors %.2e, CE %.2e, worst gradient '
-          '%.2e (%s; fp32 floor %.2e), oracle %.0f s' % (T, ef, floor_f, elp, ece, eg, gname, floor_g, secs))
-    print('worst gradients:', top)
+    _record(cfg=3, per_layer=per_layer)
     for r in per_layer:
         assert _within(r['forward_rel'], r['forward_floor_f32'], TOL_F), r
         assert _within(r['worst_grad_rel'], r['worst_grad_floor_f32'], TOL_G), r
         for g in r['grads_above_bound']:
             assert _within(g['rel'], g['floor_f32'], TOL_G), (r['layer'], g)
-    assert ece < TOL_F and elp < TOL_F
-    assert _within(ef, floor_f, TOL_F), (ef, floor_f)
-    assert _within(eg, floor_g, TOL_G), (gname, eg, floor_g)
-    assert agree > 0.9999
 
 
 def _edge_states(layer, t0, t1):

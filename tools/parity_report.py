@@ -8,7 +8,7 @@ recs = [json.loads(l) for l in open(os.path.join(ROOT, 'gpurun_out', 'parity_%s.
 dst = os.path.join(ROOT, 'profiles', 'parity_%s.json' % tag)
 by = json.load(open(dst))['configs'] if os.path.exists(dst) else {}     # a gpurun call brings back only its own records
 for r in recs:
-    by['cfg%d' % r['cfg']] = r                 # the last run of each config wins
+    by.setdefault('cfg%d' % r['cfg'], {}).update(r)     # the last run of each config wins, field by field
 out = dict(source='tests/test_gpu_longt.py on one MI355X, float64 numpy oracle (oracle/asr_oracle.py)',
            error_measure='max|a-b| / max|b| per tensor (gradients: + 1e-3 of the largest gradient tensor in the denominator)',
            precision=sorted({r.get('precision', 'f32x3') for r in by.values() if r['cfg'] < 100}),
