@@ -269,6 +269,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned* out) {
 // costs ~13 VALU instructions per element pair: a tensor that feeds several products (a layer's input: x.W_x,
 // x.W_xhat and the two weight gradients) is split once.  Products and their order are the same as on the fly:
 // results are bit-identical.
+#ifdef GEMM_STAMPS
+__device__ unsigned long long gemm_stamp_acc[8];
+#endif
 template <bool TA, bool TB, int TERMS, bool PA = false, bool PB = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K, float alpha,
                                                           const float* __restrict__ A, int lda,
@@ -336,20 +339,40 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
     // thread -> elements.  [k][row] storage: k pair kp = tid / 32 (rows k0 + 2 kp, + 1), 4 columns at 4 (tid % 32).
     //                      [row][k] storage: e = 0, 1: row (e * 256 + tid) / 4, 4 k at 4 ((e * 256 + tid) % 4).
     const int kp = tid >> 5, c4 = (tid & 31) * 4;
-    auto load_tiles_fast = [&](f32x4* ra, f32x4* rb, int k0) {
-        if (PA) load_pre(qa, A, lda, plA, AKM, k0, m0, M, K, true);
-        if (PB) load_pre(qb, B, ldb, plB, BKM, k0, n0, N, K, true);
+    // interior tiles: per-thread pointers that walk along K (set behind `kbeg` below), so that an iteration's loads
+    // cost no 64-bit address arithmetic (in-kernel stamps: 359 of an iteration's 3900 cycles went into forming them)
+    const float* wa[2]; const float* wb[2];
+    const unsigned short* wpa = nullptr; const unsigned short* wpb = nullptr;
+    size_t stepA = 0, stepB = 0;
+    auto walk_init = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int idx = e * 256 + tid;
-            if (!PA) {
-                if (AKM) ra[e] = *(const f32x4*)(A + (size_t)(k0 + 2 * kp + e) * lda + m0 + c4);
-                else     ra[e] = *(const f32x4*)(A + (size_t)(m0 + idx / 4) * lda + k0 + (idx % 4) * 4);
-            }
-            if (!PB) {
-                if (BKM) rb[e] = *(const f32x4*)(B + (size_t)(k0 + 2 * kp + e) * ldb + n0 + c4);
-                else     rb[e] = *(const f32x4*)(B + (size_t)(n0 + idx / 4) * ldb + k0 + (idx % 4) * 4);
-            }
+            wa[e] = AKM ? A + (size_t)(k0 + 2 * kp + e) * lda + m0 + c4 : A + (size_t)(m0 + idx / 4) * lda + k0 + (idx % 4) * 4;
+            wb[e] = BKM ? B + (size_t)(k0 + 2 * kp + e) * ldb + n0 + c4 : B + (size_t)(n0 + idx / 4) * ldb + k0 + (idx % 4) * 4;
+        }
+        if (PA) wpa = (const unsigned short*)A + (AKM ? (size_t)(k0 + (tid >> 4)) * lda + m0 + (tid & 15) * 8
+                                                      : (size_t)(m0 + (tid >> 1)) * lda + k0 + (tid & 1) * 8);
+        if (PB) wpb = (const unsigned short*)B + (BKM ? (size_t)(k0 + (tid >> 4)) * ldb + n0 + (tid & 15) * 8
+                                                      : (size_t)(n0 + (tid >> 1)) * ldb + k0 + (tid & 1) * 8);
+        stepA = AKM ? (size_t)BK * lda : BK;
+        stepB = BKM ? (size_t)BK * ldb : BK;
+    };
+    auto load_tiles_fast = [&](f32x4* ra, f32x4* rb) {      // loads the tile the pointers stand on, then steps them
+        if (PA) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qa[p] = *(const u32x4s*)(wpa + (size_t)p * plA);
+            wpa += stepA;
+        }
+        if (PB) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qb[p] = *(const u32x4s*)(wpb + (size_t)p * plB);
+            wpb += stepB;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!PA) { ra[e] = *(const f32x4*)wa[e]; wa[e] += stepA; }
+            if (!PB) { rb[e] = *(const f32x4*)wb[e]; wb[e] += stepB; }
         }
     };
     auto load_tiles = [&](int k0) {
@@ -466,21 +489,43 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
     const int nk_full = (kend - kbeg) / BK;
     const bool interior = vecA && vecB && (m0 + BM <= M) && (n0 + BN <= N) && nk_full > 0;
     if (interior) {
-        load_tiles_fast(ra, rb, kbeg);
+        walk_init(kbeg);
+        load_tiles_fast(ra, rb);
         store_tiles(0);
         __syncthreads();
         // one iteration per trip, not unrolled: an unrolled pair made the register allocator move the 64 accumulator
         // registers between the halves (v_mov behind the MFMA latency).  Loads two tiles ahead and an MFMA / split-VALU
         // interleave (sched_group_barrier) were measured and changed nothing: 162 vs 170 TFLOP/s
+#ifdef GEMM_STAMPS      // diagnostic build only (tools/ubench/gemm_stamps.hip): where an iteration's cycles go
+        unsigned long long st_[5] = {0, 0, 0, 0, 0};
+#define GST_(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - sp_; sp_ = n_; } while (0)
+        unsigned long long sp_ = __builtin_amdgcn_s_memtime();
+#else
+#define GST_(i) do { } while (0)
+#endif
 #pragma unroll 1
         for (int kt = 0; kt + 1 < nk_full; ++kt) {
-            load_tiles_fast(ra, rb, kbeg + (kt + 1) * BK);
+            load_tiles_fast(ra, rb);
             __builtin_amdgcn_sched_barrier(0);
+            GST_(0);
             mfma_tile(kt);
             __builtin_amdgcn_sched_barrier(0);
+            GST_(1);
+#ifdef GEMM_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GST_(2);
+#endif
             store_tiles(kt + 1);
+            GST_(3);
             __syncthreads();
+            GST_(4);
         }
+#ifdef GEMM_STAMPS
+        if (lane == 0)
+            for (int i = 0; i < 5; ++i) atomicAdd(&gemm_stamp_acc[i], st_[i]);
+        if (tid == 0) atomicAdd(&gemm_stamp_acc[5], (unsigned long long)(nk_full - 1));
+#endif
+#undef GST_
         if (nk > nk_full) {                                 // K tail: one guarded tile
             load_tiles(kbeg + nk_full * BK);
             mfma_tile(nk_full - 1);

@@ -46,11 +46,17 @@ cases = [
     ('HyperLSTM 2x1024', 1, lambda: builders.build_deep_hyperlstm('hyper', None, None, 123, 2, 1024, 128, 64, 61, 1.0, True, 0,
                                                                   device=dev, seed=1), max(reps // 2, 4)),
 ]
+# round 3: 32 rows = two 16-row chunks per workgroup (teams) in the hyper scans, the generic LSTM forward scan and the 2-D
+# LN backward; time axis cut to 600 frames
+cases += [('cfg3 32 rows (teams)', 3, cases[0][2], max(reps // 2, 4)), ('cfg2 32 rows (teams)', 2, cases[1][2], max(reps // 2, 4)),
+          ('cfg4 32 rows (teams)', 4, cases[2][2], max(reps // 2, 4)),
+          ('per-gate LN 32 rows (teams)', 2, cases[8][2], max(reps // 2, 4))]
 bad = 0
 for name, cfg, mk, n in cases:
     net = mk()
     steploop = name.startswith(('ProjectionHyper', 'ScalingHyper options'))
-    b = workloads.make_batch(cfg, 16, max_len=200 if steploop else None)
+    teams = '(teams)' in name
+    b = workloads.make_batch(cfg, 32 if teams else 16, max_len=200 if steploop else 600 if teams else None)
     x, m, y = t(b['x']), t(b['mask']), t(b['y'])
     iv = t(b['ivec']) if 'ivec' in b else None
     tb = net.tbptt_layers()
