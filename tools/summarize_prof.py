@@ -54,6 +54,9 @@ def main():
                                                 mu.get(k, (0, 0))[1], 100.0 * busy / (gui / 8.0 * 1024.0) if gui else 0.0,
                                                 ','.join('%.0f' % raw[c].get(k, (0, 0))[1] for c in raw)))
     for kname in ('hyper_scan_bwd_kernel', 'hyper_scan_fwd_kernel'):
+        full = [k for k in fe if kname in k and k in wr]       # template instances: 'void hyper_scan_bwd_kernel<1>'
+        if full:
+            fe[kname], wr[kname] = fe[full[0]], wr[full[0]]
         if kname in fe and kname in wr:
             lib = os.environ.get('ASR_AMD_LIB') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'asr_amd', 'libasr_amd.so')
             json.dump({'kernel': kname,
