@@ -21,9 +21,12 @@ class GradAllReduce(object):
         self.pending = []
         # ASR_DP_OVERLAP=0: no bucket leaves before the last BPTT scan has finished; finish() then reduces the whole
         # flat gradient in one collective on the main stream.  The fallback for a node on which RCCL's kernels and the
-        # persistent scans (256 workgroups, one per CU, 82 KB of LDS each) do not share the chip well: a bucket's
-        # all-reduce kernel can only run beside a scan on the LDS and wave slots that scan leaves (78 KB, 28 waves per
-        # CU), and a scan that started first is never pre-empted; measured nowhere yet (no multi-GPU node this round).
+        # persistent scans do not share the chip well.  What an RCCL workgroup finds on a CU beside a scan workgroup
+        # (code-object metadata of this library): up to 16 rows per GPU the scan holds one wave per
+        # SIMD with 232-248 of the SIMD's 512 registers per lane and 82 KB of the 160 KB of LDS, so a 256-thread
+        # workgroup of <= 264 registers and <= 78 KB fits; above 16 rows (two teams) the scan's two waves per SIMD hold
+        # 448-466 registers per lane and NO further wave fits on that CU until the launch ends: disable_overlap() is
+        # what bench.py calls then.  A scan that started first is never pre-empted.  Unmeasured (no multi-GPU node).
         self.overlap = os.environ.get('ASR_DP_OVERLAP', '1') != '0'
         if self.world > 1 and self.overlap:
             net.grad_hook = self.bucket_ready
@@ -51,6 +54,11 @@ class GradAllReduce(object):
         self.pending = []
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
+
+    def disable_overlap(self):
+        """As ASR_DP_OVERLAP=0, decided by the caller (batches above 16 rows per GPU: see __init__)."""
+        self.overlap = False
+        self.net.grad_hook = None
 
     def suspend_overlap(self):
         """Gradient accumulation over micro-batches: buckets must not leave before the last micro-batch has been

@@ -340,6 +340,8 @@ def main():
         raise SystemExit('bench.py: %d rows per GPU do not split into %d equal micro-batches' % (B_local, n_micro))
     if n_micro > 1:
         ar.suspend_overlap()        # the accumulated gradient is reduced once, after the last micro-batch
+    elif B_local > 16:
+        ar.disable_overlap()        # two teams per scan workgroup leave no registers for an RCCL wave (dp.py)
     batches = []
     sorted_lens = workloads.length_sorted_batches(3, B_local * world, args.pool) if args.length_sort else None
     t_local = []                                      # padded length of every pool batch on this rank
@@ -473,6 +475,7 @@ def main():
                                batching='length-sorted cache of 1024 utterances (LengthSortTransformer)' if args.length_sort
                                else 'independent random batches per rank (reference default: length_sort=False)',
                                scan_chunks_per_workgroup=min(2, (min(B_local, args.micro_batch) + 15) // 16),
+                               allreduce='none (1 GPU)' if world == 1 else ('per-layer buckets overlapped with BPTT' if net.grad_hook is not None else 'one collective after the last BPTT scan'),
                                gemm={'f32x3': 'fp32-grade: operands split into 3 bf16 parts, 6 bf16-MFMA partial '
                                               'products, fp32 accumulate (error vs float64 below the fp32 MFMA kernel)',
                                      'f32': 'v_mfma_f32_32x32x2_f32', 'bf16': 'operands rounded to bf16'}[precision]),
