@@ -19,7 +19,9 @@ class LstmDir(C.Structure):
     _fields_ = [('reverse', i32), ('xin', fp), ('wpack', fp), ('alpha_hid', fp), ('beta_hid', fp),
                 ('alpha_c', fp), ('beta_c', fp), ('c0', fp), ('r0', fp), ('a0', fp), ('r_out', fp), ('ld_r', i32),
                 ('gates', fp), ('cst', fp), ('ahat', fp), ('rs_a', fp), ('chat', fp), ('rs_c', fp),
-                ('dr_ext', fp), ('ld_dr', i32), ('dG', fp), ('dA', fp), ('dOut', fp)]
+                ('dr_ext', fp), ('ld_dr', i32), ('dG', fp), ('dA', fp), ('dOut', fp),
+                ('peep', fp), ('a0_until_valid', i32), ('dc_ext', fp), ('ld_dc', i32), ('dc0', fp), ('dr0', fp),
+                ('da0', fp), ('dpeep', fp)]
 
 
 class LstmScanDesc(C.Structure):

@@ -45,7 +45,22 @@ struct LstmDir {
     float* dG;               // (T,B,4N) clipped gradient wrt the gate pre-activations
     float* dA;               // (T,B,4N) gradient wrt a_t = r_{t-1}.W'   (== dG when no LN)
     float* dOut;             // (T,B,N)  clipped gradient wrt outcell (cell LN only)
+    // options of the recurrent_layers.py classes (peepholes, learn_init, only_return_hidden=False; :52-57).  Any of
+    // them set selects the OPT instantiation of the generic kernels, one 16-row chunk per workgroup.
+    const float* peep;       // (N,4) per unit: w_cell_to_ingate, w_cell_to_forgetgate, 0, w_cell_to_outgate; or null
+    int a0_until_valid;      // a0 stands in for r.W' until the row's first unmasked step, not only at step 0 (a learned
+                             // hid_init of a projected layer is carried through leading masked steps, :246-248,:239)
+    const float* dc_ext;     // backward in:  (T,B,ld_dc) dLoss/d cell_t from the layers above (cell_out returned, :275-288)
+    int ld_dc;
+    float* dc0;              // backward out: (B,N) gradient wrt the initial cell row
+    float* dr0;              // backward out: (B,N) gradient that reached r_{-1} THROUGH masked steps; the caller adds the
+                             //               first scan step's da.W'^T (that product is not formed inside the launch)
+    float* da0;              // backward out: (B,4N) da of each row's first unmasked step (zeros for an empty row)
+    float* dpeep;            // backward out: (B,N,4) per-row sums over time of dg_i c_{t-1}, dg_f c_{t-1}, 0, dg_o c_t
 };
+static inline bool lstm_dir_has_options(const LstmDir& D) {
+    return D.peep || D.a0_until_valid || D.dc_ext || D.dc0 || D.dr0 || D.da0 || D.dpeep;
+}
 
 struct LstmScanArgs {
     int T, B, N, UT, G, KS, KSP, KT;
@@ -230,7 +245,7 @@ __device__ __forceinline__ void combine_sums4(const float* st, int KS, int tid, 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int UT, int NC>
+template <int UT, int NC, bool OPT = false>
 __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -286,6 +301,12 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A)
     if (A.ln_kind && wave < UT) {
         al4 = *(const f32x4*)(D.alpha_hid + (A.ln_kind == 2 ? (size_t)(bvalid ? b : 0) * 4 * N : 0) + col4);
         if (D.beta_hid) be4 = *(const f32x4*)(D.beta_hid + col4);
+    }
+    f32x4 pe4 = {0.f, 0.f, 0.f, 0.f}, a0v = {0.f, 0.f, 0.f, 0.f};
+    bool virgin = true;                                  // OPT: no unmasked step of this row yet
+    if constexpr (OPT) {
+        if (wave < UT && D.peep) pe4 = *(const f32x4*)(D.peep + col4);
+        if (wave < UT && D.a0) a0v = *(const f32x4*)(D.a0 + (size_t)(bvalid ? b : (B - 1)) * 4 * N + col4);
     }
     group_publish(gs);
 
@@ -369,7 +390,11 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A)
         if (wave < UT) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) a4 += *(const f32x4*)(red + ((size_t)(wave * 4 + w) * 64 + lane) * 4);
-            if (step == 0 && D.a0) a4 = *(const f32x4*)(D.a0 + (size_t)bq * 4 * N + col4);
+            if constexpr (OPT) {
+                if (D.a0 && (step == 0 || (D.a0_until_valid && virgin))) a4 = a0v;
+            } else {
+                if (step == 0 && D.a0) a4 = *(const f32x4*)(D.a0 + (size_t)bq * 4 * N + col4);
+            }
         }
         float rs_a = 0.f;
         f32x4 rs_a4 = {0, 0, 0, 0};
@@ -416,8 +441,14 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A)
             } else {
                 pre = x4 + a4;
             }
-            ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf_(pre[2]); og = sigmoidf_(pre[3]);
-            c_new = fg * c + ig * gg;
+            if constexpr (OPT) {     // peepholes: in / forget gate see c_{t-1}, the out gate the new cell (:190-192,:212-213)
+                ig = sigmoidf_(pre[0] + c * pe4[0]); fg = sigmoidf_(pre[1] + c * pe4[1]); gg = tanhf_(pre[2]);
+                c_new = fg * c + ig * gg;
+                og = sigmoidf_(pre[3] + c_new * pe4[3]);
+            } else {
+                ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf_(pre[2]); og = sigmoidf_(pre[3]);
+                c_new = fg * c + ig * gg;
+            }
         }
         float outcell = c_new;
         STAMP(3);
@@ -440,7 +471,7 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A)
         }
         if (wave < UT) {
             const float r_new = og * tanhf_(outcell);
-            if (m != 0.f) { c = c_new; r = r_new; }
+            if (m != 0.f) { c = c_new; r = r_new; virgin = false; }
             {
                 const float r1 = __shfl(r, bl + 16), r2 = __shfl(r, bl + 32), r3 = __shfl(r, bl + 48);
                 if (q == 0)
@@ -730,7 +761,7 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_cln_kernel(LstmScanArg
 //   2. cell / gate gradients for its units (+ LN backward with two small stat exchanges)
 //   3. partial dr_{t-1}[b, all k] = da[b, own cols] . W'[k, own cols]^T  -> publish per destination
 // ------------------------------------------------------------------------------------------------
-template <int UT, int NC>
+template <int UT, int NC, bool OPT = false>
 __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -796,9 +827,16 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A)
     float c0v = *(own ? D.cst + row_of(0) * N + unit : dummy), c1v = *(own ? D.cst + row_of(1) * N + unit : dummy);
     const float c_init = *((own && D.c0) ? D.c0 + (size_t)bq * N + unit : dummy);
     const bool has_c0 = D.c0 != nullptr;
-    float n_m, n_dre, n_ra, n_ch, n_rc, n_c2;
+    // OPT: external cell gradient, peephole vectors, and what the learned initial rows / peepholes need at the end
+    const float* p_dce = (OPT && own && D.dc_ext) ? D.dc_ext + r00 * D.ld_dc + unit : dummy;
+    const int s_dce = (OPT && own && D.dc_ext) ? dt * B * D.ld_dc : 0;
+    const bool has_dce = OPT && D.dc_ext;
+    f32x4 pe4 = {0.f, 0.f, 0.f, 0.f}, pw = {0.f, 0.f, 0.f, 0.f}, da_first = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (OPT) { if (own && D.peep) pe4 = *(const f32x4*)(D.peep + col4); }
+    float n_m, n_dre, n_ra, n_ch, n_rc, n_c2, n_dce = 0.f;
     f32x4 n_g4, n_ah4, n_ra4;
     auto prefetch = [&]() {
+        if constexpr (OPT) n_dce = *p_dce;
         n_m = *p_m; n_g4 = *(const f32x4*)p_g; n_dre = *p_dr;
         n_ah4 = *(const f32x4*)p_ah; n_ra4 = *(const f32x4*)p_ra4; n_ra = *p_ra;
         n_ch = *p_ch; n_rc = *p_rc; n_c2 = *p_c2;
@@ -821,8 +859,10 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A)
         const f32x4 g4 = n_g4, ah4 = n_ah4, rs_a4 = n_ra4;
         const float c_new = c0v, c_prev = st > 0 ? c1v : (has_c0 ? c_init : 0.f);
         const float dre = live ? n_dre : 0.f, rs_a = n_ra, chat_v = n_ch, rs_c = n_rc;
+        if constexpr (OPT) { if (live && has_dce) dc += n_dce; }     // dLoss/d cell_t joins the carried cell gradient
         {
             const bool go = step + 1 < T;
+            if constexpr (OPT) p_dce += go ? s_dce : 0;
             p_m += go ? s_m : 0; p_g += go ? s_g : 0; p_dr += go ? s_dr : 0; p_ah += go ? s_ah : 0;
             p_ra4 += go ? s_ra4 : 0; p_ra += go ? s_ra : 0; p_ch += go ? s_ch : 0; p_rc += go ? s_rc : 0;
             prefetch();
@@ -891,12 +931,17 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A)
         }
         f32x4 dg4 = {0, 0, 0, 0};
         if (on) {
-            const float dct = dc + dcn;
+            float dct = dc + dcn;
+            dg4[3] = clipf_(do_ * og * (1.f - og), A.clip);
+            if constexpr (OPT) dct += dg4[3] * pe4[3];           // the out gate looked at the new cell
             dg4[0] = clipf_(dct * gg * ig * (1.f - ig), A.clip);
             dg4[1] = clipf_(dct * c_prev * fg * (1.f - fg), A.clip);
             dg4[2] = clipf_(dct * ig * (1.f - gg * gg), A.clip);
-            dg4[3] = clipf_(do_ * og * (1.f - og), A.clip);
             dc = dct * fg;
+            if constexpr (OPT) {
+                dc += dg4[0] * pe4[0] + dg4[1] * pe4[1];
+                pw[0] += dg4[0] * c_prev; pw[1] += dg4[1] * c_prev; pw[3] += dg4[3] * c_new;
+            }
             dr_pass = 0.f;
         } else {
             dr_pass = dr_t;
@@ -939,6 +984,7 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A)
             }
 
         }
+        if constexpr (OPT) { if (on) da_first = da4; }           // backward order: the last one kept is the row's first step
         // 3. partial dr_{prev}: B operand needs da[b][col 4e+(l>>4)] -> go through LDS
         if (wave < UT) {
 #pragma unroll
@@ -968,6 +1014,14 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A)
         if (wave < UT && bvalid && q_da) *(f32x4*)q_da = da4;
         c0v = c1v; c1v = n_c2;
         q_dg += z_dg; q_da += z_da; q_do += z_do;
+    }
+    if constexpr (OPT) {
+        if (wave < UT && bvalid) {
+            if (D.dc0) D.dc0[(size_t)b * N + unit] = dc;
+            if (D.dr0) D.dr0[(size_t)b * N + unit] = dr_pass;
+            if (D.da0) *(f32x4*)(D.da0 + (size_t)b * 4 * N + col4) = da_first;
+            if (D.dpeep) *(f32x4*)(D.dpeep + (size_t)b * 4 * N + col4) = pw;
+        }
     }
     STAMP_DUMP(A.dbg, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
@@ -1310,9 +1364,19 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
     // generic kernel's teams and 96-114 k with one launch per chunk), so larger batches take the generic kernel for
     // EVERY chunk: the two kernels sum the cell-LN statistics in different orders, and a batch's rows must not
     // depend on which launch carried them.
+    // options of the recurrent_layers.py classes: the generic kernels' OPT instantiation, one chunk per workgroup; the
+    // backward weights must then be packed with mode 1 whatever asr_lstm_bwd_pack_mode says
+    const bool opt = lstm_dir_has_options(d->dir[0]) || (d->ndir > 1 && lstm_dir_has_options(d->dir[1]));
+    for (int k = 0; k < d->ndir; ++k) {
+        const LstmDir& D = d->dir[k];
+        if (D.a0_until_valid && !D.a0) return ASR_ERR_ARG;
+        if (D.peep && (d->ln_kind || d->cell_ln)) return ASR_ERR_ARG;      // no class has both (:53 vs :555)
+        if (!backward && (D.dc_ext || D.dc0 || D.dr0 || D.da0 || D.dpeep)) return ASR_ERR_ARG;
+        if (D.dpeep && !D.peep) return ASR_ERR_ARG;
+    }
     const bool fused_cln = !backward && A.cell_ln && UT == 1 && A.KSP / 16 <= 8 && nchunk_total <= cpl &&
-                           !d->dir[0].a0 && !(d->ndir > 1 && d->dir[1].a0);
-    const bool ln2d = backward && UT == 1 && asr_lstm_bwd_pack_mode(d->N, d->ndir, d->ln_kind) == 2;
+                           !d->dir[0].a0 && !(d->ndir > 1 && d->dir[1].a0) && !opt;
+    const bool ln2d = backward && UT == 1 && !opt && asr_lstm_bwd_pack_mode(d->N, d->ndir, d->ln_kind) == 2;
     // LDS of a workgroup whose nc teams carry nc chunks: the resident weights once, the staging buffers per team
     auto lds_of = [&](int nc) -> size_t {
         if (ln2d) return ((size_t)(A.KS / 32) * 2048 + (size_t)nc * 2304) * 4 + 64;
@@ -1326,7 +1390,7 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
         const int rem = nchunk_total - c0;
         // chunks that do not fit one launch as workgroups of their own (cpl z slices) ride as teams of two inside a
         // workgroup instead of waiting for a launch of their own
-        int nc = (rem > cpl && nc_cap >= 2 && lds_of(2) <= 160 * 1024) ? 2 : 1;
+        int nc = (rem > cpl && nc_cap >= 2 && !opt && lds_of(2) <= 160 * 1024) ? 2 : 1;
         int nz = nc == 2 ? rem / 2 : rem;
         if (nz > cpl) nz = cpl;
         size_t lds = lds_of(nc);
@@ -1340,7 +1404,10 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
         if (!scan_grid_fits((size_t)A.G * d->ndir * nz, lds)) return ASR_ERR_LIMIT;
         const void* fn = nullptr;
 #define PICK_NC_(...) (nc == 2 ? (const void*)__VA_ARGS__, 2> : (const void*)__VA_ARGS__, 1>)
-        if (!backward) {
+        if (opt) {
+            if (!backward) fn = UT == 1 ? (const void*)lstm_scan_fwd_kernel<1, 1, true> : UT == 2 ? (const void*)lstm_scan_fwd_kernel<2, 1, true> : (const void*)lstm_scan_fwd_kernel<4, 1, true>;
+            else fn = UT == 1 ? (const void*)lstm_scan_bwd_kernel<1, 1, true> : UT == 2 ? (const void*)lstm_scan_bwd_kernel<2, 1, true> : (const void*)lstm_scan_bwd_kernel<4, 1, true>;
+        } else if (!backward) {
             if (fused_cln) fn = (const void*)lstm_scan_fwd_cln_kernel<1>;
             else if (UT == 1) fn = PICK_NC_(lstm_scan_fwd_kernel<1);
             else if (UT == 2) fn = PICK_NC_(lstm_scan_fwd_kernel<2);

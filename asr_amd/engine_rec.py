@@ -19,13 +19,17 @@ from .engine import DirParams
 G4R = specs.GATES_REC
 
 
-def _mk_rec(store, prefix, cls, D, N, P, F, I):
+def _mk_rec(store, prefix, cls, D, N, P, F, I, peepholes=False, learn_init=False):
     v = specs.REC_CLASSES[cls]
     dp = DirParams(store, prefix)
     K = P if P else N
     dp.add('Wx', (D, 4 * N)); dp.add('Wh', (K, 4 * N))
     if v['bias']:
         dp.add('b', (4 * N,))
+    if peepholes:                  # (N,4) per unit [w_ci, w_cf, 0, w_co]: the kernel's one 16-byte read per lane
+        dp.add('pe', (4 * N,))
+    if learn_init:
+        dp.add('c_init', (1, N)); dp.add('h_init', (1, K))
     if P:
         dp.add('Wp', (N, P))
     if v['ln'] == 'static':
@@ -47,8 +51,10 @@ def _mk_rec(store, prefix, cls, D, N, P, F, I):
              'W_alpha_cell': ('a_c', 'same'), 'W_beta_cell': ('b_c', 'same'), 'num_factors': ('b_c', 'same'),
              'W_beta_in': ('b_in', 'perm4'), 'W_beta_hid': ('b_hid', 'perm4'),
              'b_alpha_in': ('bai', 'perm4'), 'b_alpha_hid': ('bah', 'perm4'),
-             'W_beta': ('Wbt', 'perm4'), 'b_beta': ('bbt', 'perm4')}
-    for name, shape, _ in specs.rec_params(cls, D, N, F if v['cond'] else (P or None), P or None, I):
+             'W_beta': ('Wbt', 'perm4'), 'b_beta': ('bbt', 'perm4'),
+             'cell_init': ('c_init', 'same'), 'hid_init': ('h_init', 'same')}
+    for name, shape, _ in specs.rec_params(cls, D, N, F if v['cond'] else (P or None), P or None, I,
+                                           peepholes=peepholes, learn_init=learn_init):
         done = False
         for g, gn in enumerate(G4R):
             if name == 'W_in_to_' + gn:
@@ -57,6 +63,9 @@ def _mk_rec(store, prefix, cls, D, N, P, F, I):
                 dp.map(name, 'Wh', 'gatecols', g); done = True
             elif name == 'b_' + gn:
                 dp.map(name, 'b', 'gatevec', g); done = True
+        for g, gn in ((0, 'ingate'), (1, 'forgetgate'), (3, 'outgate')):
+            if name == 'W_cell_to_' + gn:
+                dp.map(name, 'pe', 'gatevec', g); done = True
         if done:
             continue
         if name == 'W_alpha_in':
@@ -73,26 +82,35 @@ class RecPair(object):
     """A forward and optionally a backward direction of one recurrent_layers.py class."""
     stateful = False
 
-    def __init__(self, net, idx, cls, D, N, clip, ndir, num_factors=None, num_prjs=None, cond_dim=0):
+    def __init__(self, net, idx, cls, D, N, clip, ndir, num_factors=None, num_prjs=None, cond_dim=0,
+                 peepholes=False, learn_init=False, only_return_final=False, only_return_hidden=True):
+        """peepholes / learn_init / only_return_final / only_return_hidden: the classes' options
+        (libs/lasagne_libs/recurrent_layers.py:52-57), defaults as there.  A layer with only_return_final returns
+        (B, out_dim) rows and can only be the caller's last step (Network chains (T*B, .) sequences)."""
         v = specs.REC_CLASSES[cls]
+        specs.rec_check_options(cls, peepholes, learn_init)
+        self.peepholes = bool(peepholes); self.learn_init = bool(learn_init)
+        self.only_return_final = bool(only_return_final); self.only_return_hidden = bool(only_return_hidden)
+        self.opt = self.peepholes or self.learn_init or not self.only_return_hidden
         self.net = net; self.idx = idx; self.kind = 'rec'; self.cls = cls; self.v = v
         self.D = D; self.N = N; self.clip = float(clip); self.ndir = ndir
         self.num_factors = num_factors; self.num_prjs = num_prjs
         self.P = specs.rec_out_width(cls, N, num_factors, num_prjs)
         self.F = num_factors if v['cond'] else 0
         self.I = cond_dim
-        self.out_dim = ndir * (self.P or N)
+        self.wdir = (self.P or N) + (0 if self.only_return_hidden else N)     # columns of one direction's output
+        self.out_dim = ndir * self.wdir
         self.ln_kind = {'none': 0, 'static': 1, 'sample': 2}[v['ln']]     # how alpha is indexed
         self.grp = 4 if v['per_gate'] else 1
         self.cell_ln = 1 if v['cell_ln'] else 0
-        self.dirs = [_mk_rec(net.store, 'L%d.%d.' % (idx, d), cls, D, N, self.P, self.F, cond_dim)
-                     for d in range(ndir)]
+        self.dirs = [_mk_rec(net.store, 'L%d.%d.' % (idx, d), cls, D, N, self.P, self.F, cond_dim, self.peepholes,
+                             self.learn_init) for d in range(ndir)]
         self.reverse = [False, True][:ndir]
 
     def spec_per_dir(self):
         v = self.v
         return specs.rec_params(self.cls, self.D, self.N, self.F if v['cond'] else (self.P or None),
-                                self.P or None, self.I)
+                                self.P or None, self.I, peepholes=self.peepholes, learn_init=self.learn_init)
 
     def describe(self):
         out = {}
@@ -102,7 +120,9 @@ class RecPair(object):
                 continue
             out[nm] = dict(kind='rec', args=dict(variant=dict(self.v), num_units=self.N, out_width=self.P,
                                                 grad_clipping=self.clip, backwards=self.reverse[d],
-                                                cls=self.cls),
+                                                cls=self.cls, peepholes=self.peepholes, learn_init=self.learn_init,
+                                                only_return_final=self.only_return_final,
+                                                only_return_hidden=self.only_return_hidden),
                            params=[r[0] for r in self.dirs[d].refmap])
         return out
 
@@ -150,8 +170,14 @@ class RecPair(object):
             else:
                 Wf = dp.p('Wh')
             c['wpk'] = ops.lstm_pack(Wf, N, 0, net.arena.get('L%d.wpk%d' % (self.idx, d), L.asr_lstm_pack_floats(N, 0)))
+            if self.learn_init:        # T.dot(ones, cell_init) / T.dot(ones, hid_init), recurrent_layers.py:246-248
+                ones = net.arena.mat('ones_col', B, 1); ones.fill_(1.0)
+                c['c0'] = ops.gemm(ones, dp.p('c_init'), self._buf('c0_%d' % d, B, N))
+                c['h0'] = ops.gemm(ones, dp.p('h_init'), self._buf('h0_%d' % d, B, P or N))
+                if P:                  # the projected initial row enters the recurrence through W_h, not through W'
+                    c['a0'] = ops.gemm(c['h0'], dp.p('Wh'), self._buf('a0_%d' % d, B, 4 * N))
             if train:
-                pm = L.asr_lstm_bwd_pack_mode(N, self.ndir, self.ln_kind + (2 if self.grp == 4 else 0))
+                pm = 1 if self.opt else L.asr_lstm_bwd_pack_mode(N, self.ndir, self.ln_kind + (2 if self.grp == 4 else 0))
                 c['wpkb'] = ops.lstm_pack(Wf, N, pm, net.arena.get('L%d.wpkb%d' % (self.idx, d),
                                                                    L.asr_lstm_pack_floats(N, pm)))
             out.append(c)
@@ -160,6 +186,7 @@ class RecPair(object):
     def forward(self, X, T, B, mask, cond, train):
         net = self.net; N = self.N; P = self.P; v = self.v; rows = T * B
         Pout = P or N
+        W = self.wdir
         Y = self._buf('Y', rows, self.out_dim)
         desc = _lib.LstmScanDesc()
         desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
@@ -198,10 +225,18 @@ class RecPair(object):
                 Dd.alpha_hid = c['al_hid'].data_ptr()
             if self.cell_ln:
                 Dd.alpha_c = dp.p('a_c').data_ptr(); Dd.beta_c = dp.p('b_c').data_ptr()
-            R = self._buf('R%d' % d, rows, N) if P else Y[:, d * N:(d + 1) * N]
+            R = self._buf('R%d' % d, rows, N) if P else Y[:, d * W:d * W + N]
             c['R'] = R
             Dd.r_out = R.data_ptr(); Dd.ld_r = R.stride(0)
             c['cst'] = self._buf('cst%d' % d, rows, N); Dd.cst = c['cst'].data_ptr()
+            if self.peepholes:
+                Dd.peep = dp.p('pe').data_ptr()
+            if self.learn_init:
+                Dd.c0 = c['c0'].data_ptr()
+                if P:
+                    Dd.a0 = c['a0'].data_ptr(); Dd.a0_until_valid = 1
+                else:
+                    Dd.r0 = c['h0'].data_ptr()
             if train:
                 c['gates'] = self._buf('gates%d' % d, rows, 4 * N); Dd.gates = c['gates'].data_ptr()
             if self.ln_kind:
@@ -212,9 +247,26 @@ class RecPair(object):
                 Dd.chat = c['chat'].data_ptr(); Dd.rs_c = c['rs_c'].data_ptr()
             ctx['d'].append(c)
         net.scan_lstm(self, desc, backward=False)
-        if P:
-            for d, dp in enumerate(self.dirs):
-                ops.gemm(ctx['d'][d]['R'], dp.p('Wp'), Y[:, d * Pout:(d + 1) * Pout])
+        for d, dp in enumerate(self.dirs):
+            c = ctx['d'][d]
+            Yd = Y[:, d * W:d * W + Pout]
+            if P:
+                ops.gemm(c['R'], dp.p('Wp'), Yd)
+                if self.learn_init and self.reverse[d]:
+                    # a row's leading masked steps of the reverse scan (its padding) hold hid_init itself, which is no
+                    # r.W_p: r is zero there, so Y += (1 - mask) * hid_init   (T.switch(mask_n, hid, hid_previous), :239)
+                    one = self._buf('one_bp', B, Pout); one.fill_(1.0)
+                    nh0 = ops.gemm(net.arena.mat('ones_col', B, 1), dp.p('h_init'), self._buf('nh0_%d' % d, B, Pout),
+                                   alpha=-1.0)
+                    ops.affine_rows(Yd, Y.stride(0), one, c['h0'], nh0, mask, B, Yd, Y.stride(0), rows, Pout)
+            if not self.only_return_hidden:          # cell_out beside hid_out (:275-288)
+                Y[:, d * W + Pout:(d + 1) * W].copy_(c['cst'])
+        if self.only_return_final:                   # hid_out[-1] in scan order (:265-266): time T-1, or 0 going backwards
+            Yf = self._buf('Yfin', B, self.out_dim)
+            for d in range(self.ndir):
+                r0 = 0 if self.reverse[d] else (T - 1) * B
+                Yf[:, d * W:(d + 1) * W].copy_(Y[r0:r0 + B, d * W:(d + 1) * W])
+            return Yf
         return Y
 
     # ---------------------------------------------------------------------------------------------
@@ -223,14 +275,22 @@ class RecPair(object):
         X, T, B, mask = ctx['X'], ctx['T'], ctx['B'], ctx['mask']
         rows = T * B
         Pout = P or N
+        W = self.wdir
         later = []
+        if self.only_return_final:                   # the gradient of hid_out[-1] (cell_out[-1]) sits on one time step
+            dYf = self._buf('dYfull', rows, self.out_dim); dYf.zero_()
+            for d in range(self.ndir):
+                r0 = 0 if self.reverse[d] else (T - 1) * B
+                dYf[r0:r0 + B, d * W:(d + 1) * W].copy_(dY[:, d * W:(d + 1) * W])
+            dY = dYf
         desc = _lib.LstmScanDesc()
         desc.T, desc.B, desc.N, desc.ndir = T, B, N, self.ndir
         desc.ln_kind, desc.cell_ln, desc.grad_clip = self.ln_kind + (2 if self.grp == 4 else 0), self.cell_ln, self.clip
         desc.mask = mask.data_ptr(); desc.mask_stride_b = mask.stride(0); desc.mask_stride_t = mask.stride(1)
         for d, dp in enumerate(self.dirs):
             c = ctx['d'][d]
-            dYd = dY[:, d * Pout:(d + 1) * Pout]
+            dYd = dY[:, d * W:d * W + Pout]
+            c['dYd'] = dYd
             if P:
                 dR = self._buf('dR%d' % d, rows, N)
                 ops.gemm(dYd, dp.p('Wp'), dR, tb=True)
@@ -255,6 +315,19 @@ class RecPair(object):
                 c['dOut'] = self._buf('dOut%d' % d, rows, N); Dd.dOut = c['dOut'].data_ptr()
             Dd.dr_ext = dR.data_ptr(); Dd.ld_dr = dR.stride(0)
             c['dG'] = self._buf('dG%d' % d, rows, 4 * N); Dd.dG = c['dG'].data_ptr()
+            if not self.only_return_hidden:
+                dC = dY[:, d * W + Pout:(d + 1) * W]
+                Dd.dc_ext = dC.data_ptr(); Dd.ld_dc = dC.stride(0)
+            if self.peepholes:
+                c['dpe'] = self._buf('dpe%d' % d, B, 4 * N)
+                Dd.peep = dp.p('pe').data_ptr(); Dd.dpeep = c['dpe'].data_ptr()
+            if self.learn_init:
+                Dd.c0 = c['c0'].data_ptr()
+                c['dc0'] = self._buf('dc0_%d' % d, B, N); Dd.dc0 = c['dc0'].data_ptr()
+                if P:
+                    c['da0'] = self._buf('da0_%d' % d, B, 4 * N); Dd.da0 = c['da0'].data_ptr()
+                else:
+                    c['dr0'] = self._buf('dr0_%d' % d, B, N); Dd.dr0 = c['dr0'].data_ptr()
         net.scan_lstm(self, desc, backward=True)
         own = v['cond'] == 'own'
         dX = self._buf('dX', rows, self.D) if (need_dx or False) else None
@@ -339,6 +412,33 @@ class RecPair(object):
         if P:
             ops.gemm(dp.p('Wp'), dWf, dp.g('Wh'), ta=True)
             ops.gemm(dWf, dp.p('Wh'), dp.g('Wp'), tb=True, beta=1.0)
+        if self.peepholes:
+            ops.colreduce(c['dpe'], dp.g('pe'), B, 4 * N)
+        if self.learn_init:
+            ops.colreduce(c['dc0'], dp.g('c_init').view(-1), B, N)
+            first = dA[(T - 1) * B:] if self.reverse[d] else dA[:B]       # the first scan step's rows
+            srow = self._buf('srow%d' % d, 1, 4 * N)
+            if P:
+                # hid_init enters through a0 = h0.W_h at each row's first unmasked step (da0), and IS the output at the
+                # masked steps before it (reverse direction: the row's padding)
+                ops.gemm(c['h0'], c['da0'], dp.g('Wh'), ta=True, beta=1.0)
+                ops.colreduce(c['da0'], srow.view(-1), B, 4 * N)
+                ops.gemm(srow, dp.p('Wh'), dp.g('h_init'), tb=True)
+                if self.reverse[d]:
+                    Pw = P
+                    zero = self._buf('zero_bp', B, Pw); zero.zero_()
+                    one = self._buf('one_bp', B, Pw); one.fill_(1.0)
+                    mone = self._buf('mone_bp', B, Pw); mone.fill_(-1.0)
+                    E = self._buf('invmask%d' % d, rows, Pw)
+                    dYd = c['dYd']
+                    ops.affine_rows(dYd, dYd.stride(0), zero, one, mone, self.ctx['mask'], B, E, Pw, rows, Pw)
+                    ops.colreduce(dYd, dp.g('h_init').view(-1), rows, Pw, y=E, accumulate=True, ldx=dYd.stride(0), ldy=Pw)
+            else:
+                # gradient wrt r0 = what passed through masked steps + the first scan step's da.W_h^T
+                ops.gemm(c['h0'], first, dp.g('Wh'), ta=True, beta=1.0)
+                ops.colreduce(first, srow.view(-1), B, 4 * N)
+                ops.gemm(srow, dp.p('Wh'), dp.g('h_init'), tb=True)
+                ops.colreduce(c['dr0'], dp.g('h_init').view(-1), B, N, accumulate=True)
         if v['bias'] and not v['cond']:
             ops.colreduce(dG, dp.g('b'), rows, 4 * N)
         if self.cell_ln:

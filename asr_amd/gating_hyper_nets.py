@@ -85,8 +85,14 @@ class CondLayerHandle(object):
 
 def _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dropout, plain_cls,
                cond_cls=None, num_conds=0, num_factors=None, num_prjs=None, cond_dim=0, is_bidir=True,
-               device=None, seed=0, training_dropout_ok=False):
+               device=None, seed=0, training_dropout_ok=False, rec_options=None):
+    """rec_options: peepholes / learn_init / only_return_hidden of the plain_cls layers (recurrent_layers.py:52-57; no
+    builder of models/gating_hyper_nets.py sets them).  only_return_final yields one row per utterance and does not
+    chain into this frame-level network: use RecPair directly."""
     from .engine_rec import RecPair
+    rec_options = dict(rec_options or {})
+    if rec_options.get('only_return_final'):
+        raise ValueError('only_return_final does not chain into a frame-level network; call RecPair directly')
     net = Network(device or 'cuda:0')
     net.dropout = _check_dropout(dropout)
     ndir = 2 if is_bidir else 1
@@ -97,7 +103,7 @@ def _build_rec(num_inputs, num_outputs, num_layers, num_units, grad_clipping, dr
     for l in range(num_layers):
         cls = cond_cls if (cond_cls and l < num_conds) else plain_cls
         pair = RecPair(net, len(net.pairs), cls, D, num_units, grad_clipping, ndir, num_factors=num_factors,
-                       num_prjs=num_prjs, cond_dim=cond_dim)
+                       num_prjs=num_prjs, cond_dim=cond_dim, **(rec_options if cls == plain_cls else {}))
         net.add_pair(pair, [pair.spec_per_dir()] * ndir)
         if cls == cond_cls:
             cond_layers += [CondLayerHandle(pair, d) for d in range(ndir)]

@@ -158,9 +158,23 @@ def rec_out_width(cls, N, num_factors=None, num_prjs=None):
     return num_prjs
 
 
-def rec_params(cls, D, N, num_factors=None, num_prjs=None, cond_dim=0):
-    """(name, shape, init) in add_param order for a class of REC_CLASSES (peepholes=False and
-    learn_init=False, the defaults every builder of models/gating_hyper_nets.py uses)."""
+REC_PEEPHOLE_CLASSES = ('LSTMLayer', 'ProjectLSTMLayer', 'ProjectLSTM_v0_1_Layer', 'RegularLSTM_v0_1_Layer')
+
+
+def rec_check_options(cls, peepholes=False, learn_init=False):
+    """The classes that take the option at all (recurrent_layers.py:53,298,1876,3228 peepholes; learn_init: every
+    class without conditioning, e.g. :52,:555; the conditioned classes keep constant zero initial rows, :909-918)."""
+    if peepholes and cls not in REC_PEEPHOLE_CLASSES:
+        raise ValueError('%s has no peepholes option' % cls)
+    if learn_init and REC_CLASSES[cls]['cond']:
+        raise ValueError('%s has no learn_init option' % cls)
+
+
+def rec_params(cls, D, N, num_factors=None, num_prjs=None, cond_dim=0, peepholes=False, learn_init=False):
+    """(name, shape, init) of the TRAINABLE parameters in add_param order for a class of REC_CLASSES.  The builders of
+    models/gating_hyper_nets.py use peepholes=False, learn_init=False; with peepholes the three cell-to-gate vectors
+    follow the gate parameters (:112-123), with learn_init the initial rows close the list (:125-135)."""
+    rec_check_options(cls, peepholes, learn_init)
     v = REC_CLASSES[cls]
     P = rec_out_width(cls, N, num_factors, num_prjs)
     K = P if P else N
@@ -170,6 +184,8 @@ def rec_params(cls, D, N, num_factors=None, num_prjs=None, cond_dim=0):
         out += [('W_in_to_' + g, (D, N), 'orthogonal'), ('W_hid_to_' + g, (K, N), 'orthogonal')]
         if v['bias']:
             out.append(('b_' + g, (N,), ('const', 1.0 if g == 'forgetgate' else 0.0)))
+    if peepholes:
+        out += [('W_cell_to_' + g, (N,), ('uniform', 0.1)) for g in ('ingate', 'forgetgate', 'outgate')]
     if P and v['cond']:
         out.append(('W_hid_prj', (N, P), 'orthogonal'))
     if v['ln'] == 'static':
@@ -194,6 +210,8 @@ def rec_params(cls, D, N, num_factors=None, num_prjs=None, cond_dim=0):
             out += [('W_alpha_cell', (N,), ('const', 1.0)), ('num_factors', (N,), ('const', 0.0))]   # for pickles)
     if P and not v['cond']:
         out.append(('W_hid_prj', (N, P), 'orthogonal'))
+    if learn_init:
+        out += [('cell_init', (1, N), ('const', 0.0)), ('hid_init', (1, K), ('const', 0.0))]
     return out
 
 

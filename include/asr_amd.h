@@ -200,6 +200,20 @@ typedef struct asr_lstm_dir {
     float* dG;                /* (T,B,4N) */
     float* dA;                /* (T,B,4N) LN only */
     float* dOut;              /* (T,B,N)  cell LN only */
+    /* Options of the recurrent_layers.py classes (libs/lasagne_libs/recurrent_layers.py:52-57); all NULL / 0 by default.
+     * Any of them set runs the generic kernels' option form, one 16-row chunk per workgroup, and the backward weights
+     * must be packed with mode 1 whatever asr_lstm_bwd_pack_mode returns. */
+    const float* peep;        /* (N,4) per unit [w_cell_to_ingate, w_cell_to_forgetgate, 0, w_cell_to_outgate] (:112-123,
+                               * :190-192,:212-213); classes without layer norm only */
+    int a0_until_valid;       /* a0 replaces r.W' until the row's first unmasked step (learned hid_init of a projected
+                               * layer held through leading masked steps, :246-248 with :239) */
+    const float* dc_ext;      /* backward in: (T,B,ld_dc) dLoss/d cell_t (only_return_hidden=False, :275-288) or NULL */
+    int ld_dc;
+    float* dc0;               /* backward out (B,N): gradient wrt the initial cell rows (learn_init, :125-129) */
+    float* dr0;               /* backward out (B,N): gradient that reached r_{-1} through masked steps; add the first scan
+                               * step's dA . W'^T for the whole gradient wrt r0 */
+    float* da0;               /* backward out (B,4N): dA of each row's first unmasked step */
+    float* dpeep;             /* backward out (B,N,4): per-row sums over time of [dG_i c_{t-1}, dG_f c_{t-1}, 0, dG_o c_t] */
 } asr_lstm_dir;
 
 typedef struct asr_lstm_scan_desc {

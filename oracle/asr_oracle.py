@@ -98,11 +98,18 @@ def lstm_scan_fwd(xin, mask, p, spec, c0=None, h0=None):
             gates = xin[t] + a
         if p.get('b') is not None:
             gates = gates + p['b']
-        i = _sig(gates[:, 0 * N:1 * N])
-        f = _sig(gates[:, 1 * N:2 * N])
+        pe = p.get('peep')            # (w_ci, w_cf, w_co): recurrent_layers.py:190-192 (previous cell), :212-213 (new cell)
+        gi_, gf_ = gates[:, 0 * N:1 * N], gates[:, 1 * N:2 * N]
+        if pe is not None:
+            gi_ = gi_ + c * pe[0]; gf_ = gf_ + c * pe[1]
+        i = _sig(gi_)
+        f = _sig(gf_)
         g = np.tanh(gates[:, 2 * N:3 * N])
-        o = _sig(gates[:, 3 * N:4 * N])
         c_new = f * c + i * g
+        go_ = gates[:, 3 * N:4 * N]
+        if pe is not None:
+            go_ = go_ + c_new * pe[2]
+        o = _sig(go_)
         if spec.get('cell_ln'):
             outcell, cc = ln_fwd(c_new, p['alpha_c'], p['beta_c'])
         else:
@@ -143,7 +150,10 @@ def lstm_scan_bwd(dhid, cache, p, spec, dcell=None):
     dt = dhid.dtype
     B = dhid.shape[1]
     order = list(range(T - 1, -1, -1) if spec.get('backwards') else range(T))
-    g_ = {k: np.zeros_like(v) for k, v in p.items() if v is not None}
+    g_ = {k: np.zeros_like(v) for k, v in p.items() if v is not None and k != 'peep'}
+    pe = p.get('peep')
+    if pe is not None:
+        g_['peep'] = [np.zeros_like(w) for w in pe]
     dh = np.zeros_like(dhid[0])
     dc = np.zeros((B, N), dt)
     dxin = np.zeros((T, B, 4 * N), dt)
@@ -169,10 +179,17 @@ def lstm_scan_bwd(dhid, cache, p, spec, dcell=None):
             dc_new = dc_new + dcn
         else:
             dc_new = dc_new + dout
-        dgates = np.concatenate([dc_new * g * i * (1 - i), dc_new * c_prev * f * (1 - f),
-                                 dc_new * i * (1 - g * g), do * o * (1 - o)], axis=1)
-        dgates = _clip(dgates, clipv)
+        dgo = _clip(do * o * (1 - o), clipv)
+        if pe is not None:                 # the out gate looks at the NEW cell (:212-213)
+            dc_new = dc_new + dgo * pe[2]
+        dgates = np.concatenate([_clip(dc_new * g * i * (1 - i), clipv), _clip(dc_new * c_prev * f * (1 - f), clipv),
+                                 _clip(dc_new * i * (1 - g * g), clipv), dgo], axis=1)
         dc_prev = dc_prev + dc_new * f
+        if pe is not None:
+            dgi, dgf = dgates[:, 0 * N:1 * N], dgates[:, 1 * N:2 * N]
+            dc_prev = dc_prev + dgi * pe[0] + dgf * pe[1]
+            g_['peep'][0] += (dgi * c_prev).sum(0); g_['peep'][1] += (dgf * c_prev).sum(0)
+            g_['peep'][2] += (dgo * (f * c_prev + i * g)).sum(0)
         if p.get('b') is not None:       # (4N,) static bias, or (B,4N) per-sample beta added after LN
             g_['b'] += dgates if p['b'].ndim == 2 else dgates.sum(0)
         if ln != 'none':
@@ -390,10 +407,17 @@ def hyperlhuc_scan_bwd(dhid, x, fwd_cache, p, spec):
         dd_h = dh_new * r0 * dsc
         do = dr0 * tc
         dc_new = dc_new + dr0 * o * (1 - tc * tc)
-        dgates = np.concatenate([dc_new * g * i * (1 - i), dc_new * c_prev * f * (1 - f),
-                                 dc_new * i * (1 - g * g), do * o * (1 - o)], axis=1)
-        dgates = _clip(dgates, clipv)
+        dgo = _clip(do * o * (1 - o), clipv)
+        if pe is not None:                 # the out gate looks at the NEW cell (:212-213)
+            dc_new = dc_new + dgo * pe[2]
+        dgates = np.concatenate([_clip(dc_new * g * i * (1 - i), clipv), _clip(dc_new * c_prev * f * (1 - f), clipv),
+                                 _clip(dc_new * i * (1 - g * g), clipv), dgo], axis=1)
         dc_prev = dc_prev + dc_new * f
+        if pe is not None:
+            dgi, dgf = dgates[:, 0 * N:1 * N], dgates[:, 1 * N:2 * N]
+            dc_prev = dc_prev + dgi * pe[0] + dgf * pe[1]
+            g_['peep'][0] += (dgi * c_prev).sum(0); g_['peep'][1] += (dgf * c_prev).sum(0)
+            g_['peep'][2] += (dgo * (f * c_prev + i * g)).sum(0)
         dxproj[t] = dgates
         g_['W_h'] += h_prev.T @ dgates
         dh_prev = dh_prev + dgates @ p['W_h'].T
@@ -920,8 +944,15 @@ class RecLayerO(OracleLayer):
       beta before LN (added to x.W)       :968, :1233;   beta after LN :2824, :4937
       static LN + b_stacked               :711-713, :2276-2278;  per-gate LN :2531-2532, :3113-3114
       cell LN                             :740, :2305, :2849;    projection :748"""
-    def __init__(self, P, variant, num_units, out_width=0, grad_clipping=0, backwards=False, cls=None):
+    def __init__(self, P, variant, num_units, out_width=0, grad_clipping=0, backwards=False, cls=None,
+                 peepholes=False, learn_init=False, only_return_final=False, only_return_hidden=True):
+        """Options of the classes (:52-57): peepholes (LSTMLayer, ProjectLSTMLayer, *_v0_1 plain classes), learn_init
+        (every class without conditioning: cell_init (1,N), hid_init (1,K) rows broadcast over the batch, :246-248),
+        only_return_final (hid_out[-1] in scan order, :265-266), only_return_hidden=False (cell_out appended,
+        :275-288)."""
         self.P = P; self.v = variant; self.N = num_units; self.Pw = out_width
+        self.peepholes = peepholes; self.learn_init = learn_init
+        self.only_return_final = only_return_final; self.only_return_hidden = only_return_hidden
         v = variant
         self.spec = dict(N=num_units, P=out_width, ln=v['ln'], per_gate=v['per_gate'], cell_ln=v['cell_ln'],
                          grad_clip=grad_clipping, backwards=backwards)
@@ -961,18 +992,46 @@ class RecLayerO(OracleLayer):
         if v['cell_ln']:
             p['alpha_c'] = P['W_alpha_cell']
             p['beta_c'] = P['num_factors'] if v['cond'] else P['W_beta_cell']
+        if self.peepholes:
+            p['peep'] = (P['W_cell_to_ingate'], P['W_cell_to_forgetgate'], P['W_cell_to_outgate'])
         self.p = p
-        hid, _, self.cache = lstm_scan_fwd(xin, m, p, self.spec)
-        return _tm(hid)
+        c0 = h0 = None
+        if self.learn_init:
+            ones = np.ones((x.shape[0], 1), xin.dtype)
+            c0 = ones @ P['cell_init']; h0 = ones @ P['hid_init']
+        hid, cell, self.cache = lstm_scan_fwd(xin, m, p, self.spec, c0, h0)
+        last = 0 if self.spec['backwards'] else hid.shape[0] - 1
+        self._shape = hid.shape
+        if self.only_return_final:
+            hid, cell = hid[last], cell[last]
+        else:
+            hid, cell = _tm(hid), _tm(cell)
+        return hid if self.only_return_hidden else np.concatenate([hid, cell], axis=-1)
 
     def get_sample_feat(self):
         return self.s
 
     def backward(self, dy):
         P = self.P; v = self.v
-        dxin, g, _ = lstm_scan_bwd(_tm(dy), self.cache, self.p, self.spec)
+        Tn, Bn, Pn = self._shape
+        dcell = None
+        if not self.only_return_hidden:
+            dy, dcell = dy[..., :Pn], dy[..., Pn:]
+        if self.only_return_final:
+            last = 0 if self.spec['backwards'] else Tn - 1
+            full = np.zeros((Tn, Bn, Pn), dy.dtype); full[last] = dy; dy = full
+            if dcell is not None:
+                full = np.zeros((Tn, Bn, self.N), dy.dtype); full[last] = dcell; dcell = full
+        else:
+            dy = _tm(dy)
+            dcell = _tm(dcell) if dcell is not None else None
+        dxin, g, (dc0, dh0) = lstm_scan_bwd(dy, self.cache, self.p, self.spec, dcell)
         T, B, D = self.x.shape
         G = {}
+        if self.peepholes:
+            G['W_cell_to_ingate'], G['W_cell_to_forgetgate'], G['W_cell_to_outgate'] = g['peep']
+        if self.learn_init:
+            G['cell_init'] = dc0.sum(0, keepdims=True); G['hid_init'] = dh0.sum(0, keepdims=True)
         _unstack_into(G, 'W_hid_to_{}', GATES_REC, g['W_h'])
         _unstack_into(G, 'W_in_to_{}', GATES_REC, self.x.reshape(T * B, D).T @ dxin.reshape(T * B, -1))
         if self.Pw:

@@ -225,7 +225,8 @@ def _pool_max_relu(src, mask, P):                  # :1468-1470 / :1733-1735 (ma
     return _TheanoMax.apply(li)
 
 
-def rec_layer(P, cls, x, mask, N, clip=0, backwards=False, cond=None):
+def rec_layer(P, cls, x, mask, N, clip=0, backwards=False, cond=None, peepholes=False, learn_init=False,
+              only_return_final=False, only_return_hidden=True):
     W_in = _cat(P, 'W_in_to_{}', G_R); W_hid = _cat(P, 'W_hid_to_{}', G_R)
     K = W_hid.shape[0]
     inp = x.transpose(0, 1)
@@ -279,9 +280,16 @@ def rec_layer(P, cls, x, mask, N, clip=0, backwards=False, cond=None):
             gates = gate_ln(input_n, alpha_in) + gate_ln(hw, alpha_hid) + beta          # :3113-3115
         else:                                                          # sample_ln, beta already in input_n
             gates = ln(input_n, alpha_in) + ln(hw, alpha_hid)          # :976-977, :1241-1242
-        ig, fg, ci, og = [grad_clip(gates[:, k * N:(k + 1) * N], clip) for k in range(4)]
+        ig, fg, ci, og = [gates[:, k * N:(k + 1) * N] for k in range(4)]
+        if peepholes:                                                  # :190-192
+            ig = ig + cell_previous * P['W_cell_to_ingate']
+            fg = fg + cell_previous * P['W_cell_to_forgetgate']
+        ig, fg, ci = grad_clip(ig, clip), grad_clip(fg, clip), grad_clip(ci, clip)
         ig = torch.sigmoid(ig); fg = torch.sigmoid(fg); ci = torch.tanh(ci)
         cell = fg * cell_previous + ig * ci
+        if peepholes:                                                  # :212-213
+            og = og + cell * P['W_cell_to_outgate']
+        og = grad_clip(og, clip)
         if 'W_alpha_cell' in P:                                        # :740, :2305, :2849
             outcell = ln(cell, P['W_alpha_cell'], P['num_factors'] if 'num_factors' in P else P['W_beta_cell'])
         else:
@@ -295,10 +303,22 @@ def rec_layer(P, cls, x, mask, N, clip=0, backwards=False, cond=None):
         hid = torch.where(mask_n != 0, hid, hid_previous)
         return [cell, hid]
 
-    init = [torch.zeros(B, N, dtype=x.dtype), torch.zeros(B, K, dtype=x.dtype)]
-    _, hid_out = _scan(step, [inp, m], init, backwards)
-    hid_out = hid_out.transpose(0, 1)
-    return hid_out.flip(1) if backwards else hid_out
+    if learn_init:                                                     # :246-248
+        ones = torch.ones(B, 1, dtype=x.dtype)
+        init = [ones @ P['cell_init'], ones @ P['hid_init']]
+    else:
+        init = [torch.zeros(B, N, dtype=x.dtype), torch.zeros(B, K, dtype=x.dtype)]
+    cell_out, hid_out = _scan(step, [inp, m], init, backwards)
+
+    def shape_out(seq):                                                # :265-273 (and :278-286 for the cells)
+        if only_return_final:
+            return seq[-1]
+        seq = seq.transpose(0, 1)
+        return seq.flip(1) if backwards else seq
+    hid_out = shape_out(hid_out)
+    if only_return_hidden:
+        return hid_out
+    return torch.cat([hid_out, shape_out(cell_out)], dim=-1)           # :288
 
 
 def seqsum_lhuc_net(ss, layers, x, mask, N, npl, clip=0):

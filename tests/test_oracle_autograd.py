@@ -96,6 +96,37 @@ def test_recurrent_layers_family(cls, backwards, clip):
     _check(lay, lambda Pt, x, m, c: R.rec_layer(Pt, cls, x, m, N, clip, backwards, c), P, b['x'], b['mask'], cond)
 
 
+REC_OPTION_CASES = [
+    ('LSTMLayer', dict(peepholes=True)), ('ProjectLSTMLayer', dict(peepholes=True, learn_init=True)),
+    ('ProjectLSTM_v0_1_Layer', dict(peepholes=True, only_return_hidden=False)),
+    ('RegularLSTM_v0_1_Layer', dict(peepholes=True, learn_init=True, only_return_final=True)),
+    ('LSTMLayer', dict(learn_init=True)), ('LayerNormProjectLSTMLayer', dict(learn_init=True)),
+    ('LayerNormProjectLSTM_v0_2_Layer', dict(learn_init=True, only_return_hidden=False)),
+    ('LayerNormLSTMLayer', dict(learn_init=True, only_return_final=True, only_return_hidden=False)),
+    ('LayerNormRegularLSTM_v0_1_Layer', dict(learn_init=True)),
+    ('CondLayerNormProjectLSTMLayer', dict(only_return_final=True)),
+    ('InputCondLayerNormLSTMLayer', dict(only_return_hidden=False)),
+    ('CondLayerNormProjectLSTM_v0_2_Layer', dict(only_return_final=True, only_return_hidden=False)),
+]
+
+
+@pytest.mark.parametrize('backwards', [False, True])
+@pytest.mark.parametrize('clip', [0, 0.3])
+@pytest.mark.parametrize('cls,opts', REC_OPTION_CASES)
+def test_recurrent_layers_options(cls, opts, backwards, clip):
+    """peepholes / learn_init / only_return_final / only_return_hidden=False (recurrent_layers.py:52-57,112-135,
+    190-192,212-213,246-248,265-288) on the oracle's variant-table layer against the torch transliteration."""
+    rng = np.random.default_rng(23)
+    v = specs.REC_CLASSES[cls]
+    po = {k: opts[k] for k in ('peepholes', 'learn_init') if k in opts}
+    P = make_params(rng, specs.rec_params(cls, D, N, F if v['cond'] else PJ, PJ, I, **po), perturb=0.2, scale=1.5)
+    Pw = specs.rec_out_width(cls, N, F if v['cond'] else PJ, PJ)
+    b = make_batch(rng, B, T, D, C, I=I)
+    lay = O.RecLayerO(P, v, N, Pw, clip, backwards, **opts)
+    cond = b['ivec'] if v['cond'] == 'ext' else None
+    _check(lay, lambda Pt, x, m, c: R.rec_layer(Pt, cls, x, m, N, clip, backwards, c, **opts), P, b['x'], b['mask'], cond)
+
+
 @pytest.mark.parametrize('backwards', [False, True])
 @pytest.mark.parametrize('clip', [0, 0.3])
 def test_hyper_layer(backwards, clip):
