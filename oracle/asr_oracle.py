@@ -407,17 +407,10 @@ def hyperlhuc_scan_bwd(dhid, x, fwd_cache, p, spec):
         dd_h = dh_new * r0 * dsc
         do = dr0 * tc
         dc_new = dc_new + dr0 * o * (1 - tc * tc)
-        dgo = _clip(do * o * (1 - o), clipv)
-        if pe is not None:                 # the out gate looks at the NEW cell (:212-213)
-            dc_new = dc_new + dgo * pe[2]
-        dgates = np.concatenate([_clip(dc_new * g * i * (1 - i), clipv), _clip(dc_new * c_prev * f * (1 - f), clipv),
-                                 _clip(dc_new * i * (1 - g * g), clipv), dgo], axis=1)
+        dgates = np.concatenate([dc_new * g * i * (1 - i), dc_new * c_prev * f * (1 - f),
+                                 dc_new * i * (1 - g * g), do * o * (1 - o)], axis=1)
+        dgates = _clip(dgates, clipv)
         dc_prev = dc_prev + dc_new * f
-        if pe is not None:
-            dgi, dgf = dgates[:, 0 * N:1 * N], dgates[:, 1 * N:2 * N]
-            dc_prev = dc_prev + dgi * pe[0] + dgf * pe[1]
-            g_['peep'][0] += (dgi * c_prev).sum(0); g_['peep'][1] += (dgf * c_prev).sum(0)
-            g_['peep'][2] += (dgo * (f * c_prev + i * g)).sum(0)
         dxproj[t] = dgates
         g_['W_h'] += h_prev.T @ dgates
         dh_prev = dh_prev + dgates @ p['W_h'].T
