@@ -55,7 +55,7 @@ class ScalingDir(C.Structure):
     _fields_ = [('reverse', i32)] + [(n, fp) for n in (
         'inner_in', 'outer_in', 'Wio', 'S', 's', 'Woo', 'wpeep', 'lna_i', 'lnb_i', 'lna_o', 'lnb_o', 'init', 'hid',
         'gi', 'go', 'ci', 'co', 'xh_i', 'xh_o', 'rs_i', 'rs_o', 'sc', 'a',
-        'dhid', 'dgi', 'dgo', 'dsc', 'da', 'dh', 'dy_i', 'dy_o', 'dpeep', 'dinit')]
+        'dhid', 'dgi', 'dgo', 'dsc', 'da', 'dh', 'dy_i', 'dy_o', 'dpeep', 'dinit', 'tg0', 'dgi0')]
 
 
 class ScalingDesc(C.Structure):

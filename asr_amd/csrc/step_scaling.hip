@@ -42,6 +42,12 @@ struct ScalDir {                // mirrored in include/asr_amd.h (asr_scaling_di
     float *dy_i, *dy_o;         // (T,B,5H) / (T,B,5N) clipped gradients at the layer-norm outputs (LN only)
     float* dpeep;               // (T,B,3H) d gate * cell for the inner peepholes (i, f, o); null without peepholes
     float* dinit;               // (B,2H+2N) gradient wrt the initial state rows, per batch row; may be null
+    // EqualScaleHyperLSTMLayer with learn_init (hyper_layers.py:1782-1788): its learned inner_hid_init lives in the
+    // PROJECTED space, while the inner state carried here is the unprojected one (the projection is folded into Wio / S)
+    const float* tg0;           // (4H) inner_hid_init . W_inner_hid_to_inner: added to the inner gates of a row as long as
+                                // its previous state is still the initial one (first step, or masked so far); null = none
+    float* dgi0;                // (Btot,4H) backward out: d inner gate pre-activations of each row's first unmasked step
+                                // (rows without one are left untouched: clear beforehand); null = not wanted
 };
 
 struct ScalArgs {
@@ -107,6 +113,8 @@ __global__ __launch_bounds__(256) void scal_cell_fwd_kernel(ScalArgs A) {
     const bool on = A.mask[(size_t)(A.b0 + b) * A.msb + (size_t)t * A.mst] != 0.f;
     const float* cprev_p = tp < 0 ? A.c0[OUTER] + wr * U : (OUTER ? D.co : D.ci) + rowp * U;
     const float* hprev_p = tp < 0 ? A.h0 + wr * W + off : D.hid + rowp * W + off;
+    // left-aligned masks: the previous scan step masked (or none) means no step of this row has run yet
+    const bool virgin = !OUTER && D.tg0 && (tp < 0 || A.mask[(size_t)(A.b0 + b) * A.msb + (size_t)tp * A.mst] == 0.f);
     const float* lna = OUTER ? D.lna_o : D.lna_i;
     const float* lnb = OUTER ? D.lnb_o : D.lnb_i;
     float* gsv = (OUTER ? D.go : D.gi) + row * 4 * U;
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(256) void scal_cell_fwd_kernel(ScalArgs A) {
                 pk[u][k] = A.NS == 4 ? sc[12 * N + k * N + n] : 0.f;
             } else {
                 pre[u][k] = D.inner_in[row * 4 * H + k * H + n] + A.tg[wr * 4 * H + k * H + n];        // :973-975
+                if (virgin) pre[u][k] += D.tg0[k * H + n];
                 pk[u][k] = D.wpeep ? D.wpeep[k * H + n] : 0.f;
             }
         }
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(256) void scal_cell_bwd_kernel(ScalArgs A) {
     const float* cprev_p = tp < 0 ? A.c0[OUTER] + wr * U : (OUTER ? D.co : D.ci) + rowp * U;
     const float* cnew_p = (OUTER ? D.co : D.ci) + row * U;
     float* dhprev_p = tp < 0 ? A.dh0 + wr * W + off : D.dh + rowp * W + off;
+    const bool first_on = !OUTER && D.dgi0 && on && (tp < 0 || A.mask[(size_t)(A.b0 + b) * A.msb + (size_t)tp * A.mst] == 0.f);
     const float* lna = OUTER ? D.lna_o : D.lna_i;
     const float* lnb = OUTER ? D.lnb_o : D.lnb_i;
     const float* gsv = (OUTER ? D.go : D.gi) + row * 4 * U;
@@ -333,6 +343,7 @@ __global__ __launch_bounds__(256) void scal_cell_bwd_kernel(ScalArgs A) {
                 if (A.NS == 4) ds[12 * N + k * N + n] = k == 2 ? 0.f : dg * (k == 3 ? cn[u] : cp[u]);   // no map for the cell gate
             } else {
                 D.dgi[i4] = dg;
+                if (first_on) D.dgi0[(size_t)(A.b0 + b) * 4 * H + k * H + n] = dg;
             }
         }
         if (!OUTER && D.dpeep) {

@@ -418,7 +418,7 @@ class ScalingStepPair(object):
 # ------------------------------------------------------------------------------------------------
 # EqualScaleHyperLSTMLayer (libs/lasagne_libs/hyper_layers.py:1207-1890)
 # ------------------------------------------------------------------------------------------------
-def _mk_equal_scale(store, prefix, D, N, H, peep, ln):
+def _mk_equal_scale(store, prefix, D, N, H, peep, ln, learn_init=False):
     """Store tensors in the reference's shapes (gate-major concatenations) and the reference parameters as views of them,
     in the add_param order of specs.equal_scale_hyper_params.  U = N is the inner cell's width, H the projected one."""
     NS = 4 if peep else 3
@@ -430,6 +430,8 @@ def _mk_equal_scale(store, prefix, D, N, H, peep, ln):
     if ln:
         dp.add('lna_i', (5, U)); dp.add('lnb_i', (5, U))
     dp.add('P', (U, H))
+    if learn_init:                 # the kernels' initial rows [inner cell | unprojected inner hid = 0 | outer cell | outer hid]
+        dp.add('init', (2 * U + 2 * N,)); dp.add('h_init', (1, H))
     dp.add('Wox', (D, 4 * N)); dp.add('Woo', (N, 4 * N)); dp.add('S', (H, NS * 4 * N)); dp.add('s', (NS * 4 * N,))
     if ln:
         dp.add('lna_o', (5, N)); dp.add('lnb_o', (5, N))
@@ -451,7 +453,10 @@ def _mk_equal_scale(store, prefix, D, N, H, peep, ln):
     for k, gn in enumerate(_LN5):
         table['W_inner_ln_' + gn] = ('lna_i', row(k)); table['b_inner_ln_' + gn] = ('lnb_i', row(k))
         table['W_outer_ln_' + gn] = ('lna_o', row(k)); table['b_outer_ln_' + gn] = ('lnb_o', row(k))
-    for name, _, _ in specs.equal_scale_hyper_params(D, H, N, peep, ln, False):
+    seg = lambda a, b: (lambda E: E[a:b].view(1, -1))
+    table.update(inner_cell_init=('init', seg(0, U)), inner_hid_init=('h_init', lambda E: E),
+                 outer_cell_init=('init', seg(2 * U, 2 * U + N)), outer_hid_init=('init', seg(2 * U + N, 2 * U + 2 * N)))
+    for name, _, _ in specs.equal_scale_hyper_params(D, H, N, peep, ln, learn_init):
         key, fn = table[name]
         dp.map(name, key, 'fn', fn)
     return dp
@@ -483,24 +488,26 @@ class EqualScaleStepPair(ScalingStepPair):
     The kernels therefore run a ScalingHyperLSTMLayer of inner width U with the folded weights; the inner hidden sequence
     is one GEMM after the loop, and the factors' gradients come from the folded ones by the product rule:
       dW_hh = P^T.dA,  dS = P^T.dS',  dP = dA.W_hh^T + dS'.S^T.
-    learn_init is not built: inner_hid_init lives in the projected space; its pre-image under the fold, h0.(P^T P)^-1.P^T,
-    costs an H x H inverse per training step and leaves a spurious dP term to cancel, for an option no caller sets."""
+    learn_init (:1782-1788): inner_hid_init is a row of the PROJECTED space, so it has no place in the unprojected state the
+    kernels carry (that segment of their initial rows stays zero).  It reaches the recurrence only as
+    inner_hid_init.W_inner_hid_to_inner at the first unmasked step of a row: the kernels add that row (asr_scaling_dir.tg0)
+    while a row's previous state is still the initial one, and hand back the inner-gate gradients of those steps (dgi0),
+    from which d inner_hid_init = (sum_b dgi0).W_hh^T and dW_hh += inner_hid_init^T.(sum_b dgi0).  The projected inner
+    hidden sequence holds inner_hid_init itself on the reverse direction's padding (masked steps before a row's first)."""
     kind = 'equalscale'
 
     def __init__(self, net, idx, D, N, H, clip, ndir, use_peepholes, use_layer_norm, learn_init):
-        if learn_init:
-            raise NotImplementedError('asr_amd: EqualScaleHyperLSTMLayer with learn_init=True is not built (the learned '
-                                      'inner_hid_init row is in the projected space; see EqualScaleStepPair)')
         if N % 4 or H % 4:
             raise ValueError('asr_amd: EqualScaleHyperLSTMLayer needs both unit counts divisible by 4')
         self.net = net; self.idx = idx
         self.D, self.N, self.Href = D, N, H
         self.H = N                                  # the kernels' inner width
-        self.peep, self.ln, self.learn_init = bool(use_peepholes), bool(use_layer_norm), False
+        self.peep, self.ln, self.learn_init = bool(use_peepholes), bool(use_layer_norm), bool(learn_init)
         self.NS = 4 if self.peep else 3
         self.clip = float(clip); self.ndir = ndir
         self.out_dim = ndir * N
-        self.dirs = [_mk_equal_scale(net.store, 'L%d.%d.' % (idx, d), D, N, H, self.peep, self.ln) for d in range(ndir)]
+        self.dirs = [_mk_equal_scale(net.store, 'L%d.%d.' % (idx, d), D, N, H, self.peep, self.ln, self.learn_init)
+                     for d in range(ndir)]
         self.kdirs = [_FoldedDir(dp) for dp in self.dirs]
         self.reverse = [False, True][:ndir]
         self.inner_grad = [None] * ndir
@@ -516,7 +523,15 @@ class EqualScaleStepPair(ScalingStepPair):
     def inner_hid(self, d):
         """(T*B, num_inner_units): the projected inner hidden sequence of the last forward."""
         u = self.ctx['d'][d]['hid'][:, :self.H]
-        return ops.gemm(u, self.dirs[d].p('P'), self._buf('ihid%d' % d, u.shape[0], self.Href))
+        ih = ops.gemm(u, self.dirs[d].p('P'), self._buf('ihid%d' % d, u.shape[0], self.Href))
+        if self.learn_init and self.reverse[d]:        # padding of the reverse scan: the carried state is inner_hid_init
+            B, Hr = self.ctx['B'], self.Href
+            one = self._buf('one_bh', B, Hr); one.fill_(1.0)
+            ones = self._buf('ones_col', B, 1); ones.fill_(1.0)
+            h0 = ops.gemm(ones, self.dirs[d].p('h_init'), self._buf('h0b%d' % d, B, Hr))
+            nh0 = ops.gemm(ones, self.dirs[d].p('h_init'), self._buf('nh0b%d' % d, B, Hr), alpha=-1.0)
+            ops.affine_rows(ih, Hr, one, h0, nh0, self.ctx['mask'], B, ih, Hr, ih.shape[0], Hr)
+        return ih
 
     def forward(self, X, T, B, mask, cond, train):
         U, Hr, N = self.H, self.Href, self.N
@@ -528,7 +543,19 @@ class EqualScaleStepPair(ScalingStepPair):
             k.fold['S'] = ops.gemm(dp.p('P'), dp.p('S'), self._buf('S_f%d' % d, U, self.NS * 4 * N))
             k.gfold['Wio'] = self._buf('gWio_f%d' % d, U + N, 4 * U)
             k.gfold['S'] = self._buf('gS_f%d' % d, U, self.NS * 4 * N)
+            if self.learn_init:
+                k.tg0 = ops.gemm(dp.p('h_init'), dp.p('Whh'), self._buf('tg0_%d' % d, 1, 4 * U))
         return ScalingStepPair.forward(self, X, T, B, mask, cond, train)
+
+    def _desc(self, T, B, mask, backward):
+        desc = ScalingStepPair._desc(self, T, B, mask, backward)
+        if self.learn_init:
+            for d, k in enumerate(self.kdirs):
+                desc.dir[d].tg0 = k.tg0.data_ptr()
+                if backward:
+                    k.dgi0 = self._buf('dgi0_%d' % d, B, 4 * self.H); k.dgi0.zero_()
+                    desc.dir[d].dgi0 = k.dgi0.data_ptr()
+        return desc
 
     def backward(self, dY, need_dx=True):
         if any(g is not None for g in self.inner_grad):     # no caller differentiates through the inner hidden sequences
@@ -545,3 +572,8 @@ class EqualScaleStepPair(ScalingStepPair):
             ops.gemm(P, gS, dp.g('S'), ta=True)
             ops.gemm(gW[:U], dp.p('Whh'), dp.g('P'), tb=True)
             ops.gemm(gS, dp.p('S'), dp.g('P'), tb=True, beta=1.0)
+            if self.learn_init:
+                dp.g('init')[U:2 * U].zero_()           # the unprojected inner hid rows are no parameter
+                srow = ops.colreduce(k.dgi0, self._buf('sdgi0_%d' % d, 1, 4 * U).view(-1), B, 4 * U).view(1, 4 * U)
+                ops.gemm(dp.p('h_init'), srow, dp.g('Whh'), ta=True, beta=1.0)
+                ops.gemm(srow, dp.p('Whh'), dp.g('h_init'), tb=True)

@@ -285,14 +285,14 @@ def deep_equal_scale_hyper_model(input_var, mask_var, num_inputs, num_outputs, n
     """deep_scaling_hyper_model's wiring (models/gating_hyper_nets.py:27-115) with EqualScaleHyperLSTMLayer
     (libs/lasagne_libs/hyper_layers.py:1207-1890) in place of ScalingHyperLSTMLayer.  The reference defines the layer but
     no model function or script instantiates it; this builder exists so that the layer has a caller with the same
-    signature as its sibling's.  learn_init=True is refused (engine_scaling.EqualScaleStepPair)."""
+    signature as its sibling's."""
     from .engine_scaling import EqualScaleStepPair
     net = Network(device or 'cuda:0')
     D = num_inputs
     inner = []
     for H, N in zip(num_inner_units_list, num_outer_units_list):
         pair = EqualScaleStepPair(net, len(net.pairs), D, N, H, grad_clipping or 0, 2, use_peepholes, use_layer_norm, learn_init)
-        net.add_pair(pair, [specs.equal_scale_hyper_params(D, H, N, use_peepholes, use_layer_norm, False)] * 2)
+        net.add_pair(pair, [specs.equal_scale_hyper_params(D, H, N, use_peepholes, use_layer_norm, learn_init)] * 2)
         inner += [InnerHidHandle(pair, d) for d in range(2)]
         D = pair.out_dim
     net.set_output(D, num_outputs, 'softmax' if use_softmax else 'logits')

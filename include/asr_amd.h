@@ -373,6 +373,10 @@ typedef struct asr_scaling_dir {
     float *dy_i, *dy_o;       /* (T,Btot,5H) / (T,Btot,5N) clipped gradients at the layer-norm outputs (LN only) */
     float* dpeep;             /* (T,Btot,3H) d gate * cell of the inner peepholes (i, f, o); NULL without peepholes */
     float* dinit;             /* (Btot,2H+2N) gradient wrt the initial rows, per batch row; may be NULL */
+    const float* tg0;         /* (4H) or NULL: added to a row's inner gates while its previous state is still the initial one.
+                               * EqualScaleHyperLSTMLayer(learn_init=True): inner_hid_init . W_inner_hid_to_inner, the learned row
+                               * being in the projected space (libs/lasagne_libs/hyper_layers.py:1782-1788,:1657) */
+    float* dgi0;              /* (Btot,4H) or NULL, backward out: dgi of each row's first unmasked step (clear beforehand) */
 } asr_scaling_dir;
 typedef struct asr_scaling_desc {
     int T, B, N, H, ndir;

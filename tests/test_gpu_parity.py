@@ -395,10 +395,10 @@ def test_equal_scale_hyper_small(peep, ln, clip):
 
 def test_equal_scale_hyper_medium_inner_hid_and_limits():
     """64 outer / 16 inner units, 18 rows (two batch chunks), T = 29, every option; the projected inner hidden sequences of
-    get_inner_hid=True against the oracle's; learn_init is refused."""
+    get_inner_hid=True against the oracle's (with learn_init: the reverse direction's padding holds inner_hid_init)."""
     from asr_amd.gating_hyper_nets import deep_equal_scale_hyper_model
     out = deep_equal_scale_hyper_model(None, None, 11, 13, [16], [64], use_peepholes=True, use_layer_norm=True,
-                                       grad_clipping=1.0, get_inner_hid=True, device=_dev(), seed=74)
+                                       learn_init=True, grad_clipping=1.0, get_inner_hid=True, device=_dev(), seed=74)
     net = out[-1]; inner = out[:-1]
     perturb_params(net, 75, 0.05)
     b = make_batch(np.random.default_rng(76), 18, 29, 11, 13)
@@ -411,8 +411,19 @@ def test_equal_scale_hyper_medium_inner_hid_and_limits():
         got = h.get_output().cpu().numpy().reshape(29, 18, -1).transpose(1, 0, 2)
         assert got.shape[-1] == 16
         assert relerr(got, onet.layers[0][k].inner_hid) < 2e-5, k
-    with pytest.raises(NotImplementedError):
-        deep_equal_scale_hyper_model(None, None, 5, 6, [4], [8], learn_init=True, device=_dev())
+
+
+@pytest.mark.parametrize('peep,ln', [(False, False), (True, True)])
+@pytest.mark.parametrize('clip', [0.0, 0.05])
+def test_equal_scale_hyper_learn_init(peep, ln, clip):
+    """learn_init=True (hyper_layers.py:1782-1788): inner_hid_init is a row of the projected space; two stacked
+    bidirectional layers, ragged lengths (the reverse direction starts on padding)."""
+    from asr_amd.gating_hyper_nets import deep_equal_scale_hyper_model
+    net = deep_equal_scale_hyper_model(None, None, 5, 6, [4, 8], [12, 8], use_peepholes=peep, use_layer_norm=ln,
+                                       learn_init=True, grad_clipping=clip, device=_dev(), seed=77)
+    perturb_params(net, 78, 0.15)
+    b = make_batch(np.random.default_rng(79), 5, 9, 5, 6, lengths=[9, 1, 4, 7, 9])
+    run_case(net, b)
 
 
 def test_step_loop_layers_more_rows_than_one_call():
