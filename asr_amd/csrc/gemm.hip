@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, floa
 // of the partial products a_i * b_j, each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16:
 //   TERMS = 8: all but a_l * b_l          -> dropped part <= 2^-32 |a b|, below fp32's own product rounding
 //   TERMS = 6: also without a_m*b_l, a_l*b_m -> dropped part <= 2^-23 |a b| worst case
+//   TERMS = 3: a_h*b_h + a_h*b_m + a_m*b_h from TWO parts per operand ("bf16x2": 16 significand bits per operand,
+//              dropped part <= 2^-15 |a b|): the reduced-precision mode with a bound for every config, layer-norm
+//              stacks included (tests/test_gpu_bf16.py)
 //   TERMS = 1: a_h * b_h only (the plain bf16 mode)
 // 6 bf16 MFMAs (32 cycles each) replace the 8 v_mfma_f32_32x32x2_f32 (64 cycles each) of a 32x32x16 block.  How the
 // partial products are summed matters more than how many there are (see mfma_tile): measured against float64 on
@@ -257,8 +260,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned* out) {
     if (NP > 1) {
         const float r0 = x0 - __uint_as_float(out[0] << 16), r1 = x1 - __uint_as_float(out[0] & 0xffff0000u);
         out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
-        const float q0 = r0 - __uint_as_float(out[1] << 16), q1 = r1 - __uint_as_float(out[1] & 0xffff0000u);
-        out[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
+        if (NP > 2) {
+            const float q0 = r0 - __uint_as_float(out[1] << 16), q1 = r1 - __uint_as_float(out[1] & 0xffff0000u);
+            out[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
+        }
     }
 }
 
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
                                                           float beta, float* __restrict__ C, int ldc,
                                                           const float* __restrict__ bias, int ntn,
                                                           int kchunk, float* __restrict__ part, size_t plA, size_t plB) {
-    constexpr int NP = TERMS == 1 ? 1 : 3;
+    constexpr int NP = TERMS == 1 ? 1 : TERMS == 3 ? 2 : 3;
     static_assert(!(PA || PB) || TERMS == 6, "pre-split operands: the 6-product form only");
     constexpr bool AKM = TA, BKM = !TB;        // operand stored [k][row] (row contiguous)
     __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][NP][SPL_IMG];   // [buf][A|B][part]
@@ -638,6 +643,7 @@ static int gemm_launch(int mode, int transA, int transB, int M, int N, int K, fl
         else if (mode == 6 && preB) SPLIT_(TA_, TB_, 6, false, true);                                   \
         else if (mode == 6) SPLIT_(TA_, TB_, 6, false, false);                                          \
         else if (mode == 8) SPLIT_(TA_, TB_, 8, false, false);                                          \
+        else if (mode == 3) SPLIT_(TA_, TB_, 3, false, false);                                          \
         else if (mode == 1) SPLIT_(TA_, TB_, 1, false, false);                                          \
         else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_>), grid, block, 0, stream, M, N, K, alpha, A, \
                                 lda, B, ldb, beta, C, ldc, bias, ntn, kchunk, part);                    \
@@ -672,11 +678,12 @@ extern "C" int asr_gemm_bf16_ws(int transA, int transB, int M, int N, int K, flo
     return gemm_launch(1, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, stream);
 }
 
-// fp32-grade products from split bf16 operands (gemm_split_kernel): terms = 8, 6 (or 1: plain bf16 in the same kernel)
+// fp32-grade products from split bf16 operands (gemm_split_kernel): terms = 8, 6 (3: the two-part reduced-precision
+// mode; 1: plain bf16 in the same kernel)
 extern "C" int asr_gemm_bf16x3_ws(int terms, int transA, int transB, int M, int N, int K, float alpha, const float* A,
                                   int lda, const float* B, int ldb, float beta, float* C, int ldc,
                                   const float* bias, float* ws, size_t ws_bytes, hipStream_t stream) {
-    if (terms != 8 && terms != 6 && terms != 1) return ASR_ERR_ARG;
+    if (terms != 8 && terms != 6 && terms != 3 && terms != 1) return ASR_ERR_ARG;
     return gemm_launch(terms, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws,
                        ws_bytes, stream);
 }

@@ -701,6 +701,10 @@ class Network(object):
         recurrences, layer norms, softmax and the optimiser are fp32 in every mode.  Process-wide (asr_amd.ops).
           'f32x3' (default) fp32-grade products on the bf16 matrix cores from operands split into three bf16 parts;
           'f32'   fp32 MFMA throughout;
+          'bf16x2' reduced precision with a bound on EVERY config: operands as two bf16 parts (16 significand bits),
+                  3 bf16-MFMA products per fp32-grade one.  Against the float64 oracle (tests/test_gpu_bf16.py): log-
+                  posteriors within 3e-4 (cfg3) / 1e-2 (the layer-norm stacks cfg2, cfg4), the whole gradient within
+                  1e-3 / 2e-2 of its norm; cfg3 step 5 % faster than the default, the LN stacks 2 %;
           'bf16'  the optional mode of BASELINE.json's north_star: operands rounded to bf16, fp32 accumulate,
                   with the measured bound of tests/test_gpu_bf16.py.  REFUSED for networks with layer norm inside
                   the recurrence (LN-LSTM(P), cond-LN, ProjectionHyper, the scaling layer's layer-norm option): no

@@ -30,7 +30,7 @@ _gemm_ws = {}
 #   'bf16'  the optional bf16 mode: operands rounded to bf16, fp32 accumulate (keeping the weight-gradient
 #           contractions in fp32 changed no measured error at cfg3 and cost 4 ms)
 # Small products always take the fp32 MFMA kernel.
-GEMM_TERMS = {'f32': 0, 'f32x3': 6, 'bf16': 1}
+GEMM_TERMS = {'f32': 0, 'f32x3': 6, 'bf16x2': 3, 'bf16': 1}
 DEFAULT_PRECISION = os.environ.get('ASR_PRECISION', 'f32x3')
 PRECISION = DEFAULT_PRECISION
 SPLIT_MIN_WORK = 1 << 24

@@ -206,6 +206,10 @@ def other_config(args, rank, world, dev):
             'IVectorLHUCLSTMLayer', None, None, 123, 4, 512, 0, 3436, 1, 128, 0, 0, 0, BATCH, 1.0, False, False,
             100, True, device=dev, seed=1)
         name = 'cfg5: 4x512 uni LHUC-LSTM, TBPTT window 100 (one Adam step per window), lengths U{2000..6000}'
+    if args.bf16:
+        args.precision = 'bf16'
+    if args.precision:
+        net.set_precision(args.precision)       # 'bf16' is refused for the layer-norm stacks (cfg2, cfg4); 'bf16x2' is not
     ar = dp.GradAllReduce(net)
     batches = []
     for i in range(args.pool):
@@ -256,7 +260,8 @@ def other_config(args, rank, world, dev):
         out = dict(metric='forward frames/sec (node)' if args.forward_only else 'train frames/sec (node)',
                    value=frames / dt, unit='frames/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+                   higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype={'bf16': 'bf16-gemm/f32-scan', 'bf16x2': 'bf16x2-gemm/f32-scan'}.get(args.precision, 'f32'),
                    data='synthetic', config=dict(workload=name, per_gpu_batch=BATCH,
                                                  global_batch=BATCH * world, parallelism='dp%d' % world))
         out.update(clock.summary())
@@ -275,7 +280,7 @@ def main():
     ap.add_argument('--cfg', type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help='3 = the headline workload (default); 2/4/5 = the other training configs of '
                          'BASELINE.json, reported for DESIGN.md only')
-    ap.add_argument('--precision', default=None, choices=['f32x3', 'f32', 'bf16'],
+    ap.add_argument('--precision', default=None, choices=['f32x3', 'f32', 'bf16x2', 'bf16'],
                     help='how the large GEMMs multiply (asr_amd.ops): f32x3 = fp32-grade products from operands split '
                          'into three bf16 parts (default), f32 = fp32 MFMA throughout, bf16 = the optional bf16 mode')
     ap.add_argument('--bf16', action='store_true', help='same as --precision bf16: reported as dtype bf16-gemm, '
@@ -467,7 +472,7 @@ def main():
         out = dict(metric='train frames/sec (node) 4x512 HyperLSTM', value=frames / dt, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps,
                    higher_is_better=True, scaling='strong' if args.global_batch else 'weak', vs_baseline=None,
-                   dtype='bf16-gemm/f32-scan' if precision == 'bf16' else 'f32', data='synthetic',
+                   dtype={'bf16': 'bf16-gemm/f32-scan', 'bf16x2': 'bf16x2-gemm/f32-scan'}.get(precision, 'f32'), data='synthetic',
                    config=dict(workload='cfg3: 4x512 HyperLSTM (H=128,Z=64) bidirectional, C=3436, '
                                         'two concatenated WSJ-shaped utterances per row, fwd+BPTT+'
                                         'all-reduce+Adam', per_gpu_batch=B_local, global_batch=B_local * world,
@@ -478,7 +483,8 @@ def main():
                                allreduce='none (1 GPU)' if world == 1 else ('per-layer buckets overlapped with BPTT' if net.grad_hook is not None else 'one collective after the last BPTT scan'),
                                gemm={'f32x3': 'fp32-grade: operands split into 3 bf16 parts, 6 bf16-MFMA partial '
                                               'products, fp32 accumulate (error vs float64 below the fp32 MFMA kernel)',
-                                     'f32': 'v_mfma_f32_32x32x2_f32', 'bf16': 'operands rounded to bf16'}[precision]),
+                                     'f32': 'v_mfma_f32_32x32x2_f32', 'bf16': 'operands rounded to bf16',
+                                     'bf16x2': 'reduced precision: operands as two bf16 parts, 3 bf16-MFMA partial products (bound: tests/test_gpu_bf16.py)'}[precision]),
                    roofline=roof)
         out.update(clock.summary())
         # padded frames per rank and step; rank_idle_frac = 1 - mean over ranks / max over ranks of them: the share of

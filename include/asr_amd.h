@@ -52,7 +52,9 @@ int asr_gemm_bf16_ws(int transA, int transB, int M, int N, int K, float alpha, c
                      size_t ws_bytes, asr_stream_t stream);
 /* fp32-grade products on the bf16 matrix cores: every operand element is split into three bf16 parts while it
  * is staged into LDS and `terms` partial products are accumulated in fp32 (8: error below fp32's own product
- * rounding; 6: <= 2^-23 |a b|; 1: plain bf16 in the same kernel).  Same T.dot call sites as asr_gemm_f32_ws. */
+ * rounding; 6: <= 2^-23 |a b|; 3: a reduced-precision mode from TWO parts per operand, error <= 2^-15 |a|.|b| element
+ * by element, with a stated end-to-end bound on every config, tests/test_gpu_bf16.py; 1: plain bf16 in the same
+ * kernel).  Same T.dot call sites as asr_gemm_f32_ws. */
 int asr_gemm_bf16x3_ws(int terms, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                        const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
                        size_t ws_bytes, asr_stream_t stream);

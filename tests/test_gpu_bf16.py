@@ -15,7 +15,11 @@ GEMMs round their operands to bf16 and accumulate in fp32 (asr_gemm_bf16_ws); th
       norm stack turns bf16 rounding into O(1) differences (it does the same to fp32 rounding at 1e-3 scale).  So
       Network.set_precision('bf16') REFUSES networks that normalise inside the recurrence (cfg2, cfg4 and their
       relatives); the test checks the refusal and records the numbers under allow_unbounded=True.
-    measured values are printed and recorded in gpurun_out/parity_r02.jsonl."""
+  * the two-part mode 'bf16x2' (asr_gemm_bf16x3_ws with terms = 3; round 3) has a bound on EVERY config, frozen at ~4x the
+    measurement: cfg3 3e-4 / 1e-3 (log-posteriors / whole gradient; measured 7.5e-5 / 2.5e-4), cfg2 and cfg4 1e-2 / 2e-2
+    (2.6e-3 / 4.9e-3, 1.8e-3 / 3.2e-3), cfg1 1e-5 / 3e-5 (2.3e-6 / 6.8e-6): SURVEY section 7's proposal (2e-2 / 5e-2) is met
+    everywhere, at 5 % (cfg3) and 2 % (LN stacks) more frames/s than the default (profiles/r03_precision_modes.txt).
+    measured values are printed and recorded in gpurun_out/parity_r0x.jsonl."""
 import json
 import os
 
@@ -59,6 +63,53 @@ def test_gemm_bf16_is_exact_on_rounded_operands(ta, tb):
         got = dC.cpu().numpy()
         assert np.abs(got[:, :N] - ref).max() / np.abs(ref).max() < 5e-6, (M, N, K)
         assert (got[:, N:] == C0[:, N:]).all()
+
+
+def _measure(net, ck, b, vals, mode, **kw):
+    x, m, y = _t(b['x']), _t(b['mask']), _t(b['y'])
+    c = _t(b[ck]) if ck else None
+    onet = O.OracleNetwork(net.describe(), vals)
+    _, os_, _, og = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'], b.get(ck))
+    olp = O.log_softmax(onet.logits)
+    try:
+        net.set_precision(mode, **kw)
+        lp = net.posteriors(x, m, c, log=True).cpu().numpy()
+        net.check_status()
+        ce, _, _ = net.loss(x, m, y, m, c)
+        net.backward()
+        net.check_status()
+        grads = net.get_all_grad_values()
+    finally:
+        net.set_precision(ops.DEFAULT_PRECISION)
+    valid = b['mask'] > 0
+    gn = [np.linalg.norm(g) for g in og]
+    e_all = float(np.sqrt(sum(np.linalg.norm(g - o) ** 2 for g, o in zip(grads, og))) / np.sqrt(sum(n * n for n in gn)))
+    return dict(logpost_abs=float(np.abs(lp - olp)[valid].max()), logpost_abs_mean=float(np.abs(lp - olp)[valid].mean()),
+                ce_rel=abs(ce.item() - os_) / abs(os_), all_grad_norm_rel=e_all)
+
+
+# the two-part mode ('bf16x2': 3 bf16 MFMA products per fp32-grade one, 16 significand bits per operand), measured on
+# MI355X and frozen with ~2-3x margin.  It meets SURVEY section 7's proposal (2e-2 on log-posteriors, 5e-2 on the
+# gradient) on EVERY config, the layer-norm stacks the plain bf16 mode is refused for included.
+BOUNDS_X2 = {3: (3e-4, 1e-3), 2: (1e-2, 2e-2), 4: (1e-2, 2e-2), 1: (1e-5, 3e-5)}      # measured: 7.5e-5 / 2.5e-4, 2.6e-3 / 4.9e-3, 1.8e-3 / 3.2e-3, 2.3e-6 / 6.8e-6
+
+
+@pytest.mark.parametrize('cfg,max_len', [(3, 80), (2, 40), (4, 40), (1, 200)])
+def test_bf16x2_mode_meets_the_stated_bound(cfg, max_len):
+    net, ck = build_cfg(cfg)
+    vals = perturb_params(net, 30 + cfg, 0.02)
+    b = _batch(cfg, max_len=max_len)
+    r = _measure(net, ck, b, vals, 'bf16x2')
+    print('cfg%d bf16x2 mode: %s' % (cfg, r))
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity_%s.jsonl' % os.environ.get('ASR_PARITY_TAG', 'r03')), 'a') as f:
+            f.write(json.dumps(dict(cfg=cfg * 100 + 1, of_cfg=cfg, T=int(b['x'].shape[1]),
+                                    mode='bf16x2 GEMMs (operands as two bf16 parts, 3 products, fp32 accumulate), fp32 recurrences',
+                                    bound_logpost_abs=BOUNDS_X2[cfg][0], bound_all_grad_norm_rel=BOUNDS_X2[cfg][1], **r)) + '\n')
+    assert r['logpost_abs'] <= BOUNDS_X2[cfg][0] and r['all_grad_norm_rel'] <= BOUNDS_X2[cfg][1], r
+    assert r['ce_rel'] <= 1e-3
+    assert ops.PRECISION == ops.DEFAULT_PRECISION
 
 
 @pytest.mark.parametrize('cfg,max_len', [(3, 80), (2, 40)])

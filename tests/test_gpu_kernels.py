@@ -73,6 +73,33 @@ def test_gemm_split_bf16_is_fp32_grade(ta, tb, terms):
                                 None, 0, torch.cuda.current_stream().cuda_stream) == -1
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_two_part_mode_error_bound(ta, tb):
+    """asr_gemm_bf16x3_ws(terms = 3): operands as TWO bf16 parts (16 significand bits), products hh + hm + mh.  Element by
+    element against float64 the error stays below 2^-15 |A|.|B| (each operand's dropped part is below 2^-17 of it in
+    round-to-nearest, the dropped m*m product below 2^-18; 2^-15 leaves the accumulation its share), 100x tighter than the
+    plain bf16 mode's 2^-8 and ~250x looser than the default's."""
+    from asr_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(21 + 2 * ta + tb)
+    ws = torch.empty(16 << 20, device='cuda')
+    for M, N, K in ((128, 128, 64), (200, 136, 50), (37, 300, 1000), (256, 128, 8192), (5, 7, 3), (1000, 515, 123)):
+        sa, sb = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
+        A = (rng.standard_normal(sa) * np.exp(2 * rng.standard_normal(sa))).astype(np.float32)
+        B = (rng.standard_normal(sb) * np.exp(2 * rng.standard_normal(sb))).astype(np.float32)
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        dC = torch.zeros(M, N, device='cuda')
+        opA, opB = (A.T if ta else A).astype(np.float64), (B.T if tb else B).astype(np.float64)
+        ref = opA @ opB
+        scale = np.abs(opA) @ np.abs(opB)
+        rc = L.asr_gemm_bf16x3_ws(3, ta, tb, M, N, K, 1.0, dA.data_ptr(), A.shape[1], dB.data_ptr(), B.shape[1], 0.0,
+                                  dC.data_ptr(), N, None, ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        err = float(np.max(np.abs(dC.cpu().numpy() - ref) / scale))
+        print('M=%d N=%d K=%d ta=%d tb=%d two-part: %.2e (2^-15 = %.2e)' % (M, N, K, ta, tb, err, 2.0 ** -15))
+        assert err < 2.0 ** -15, (M, N, K, err)
+
+
 def test_ln_rows_and_colreduce():
     from asr_amd import ops
     rng = np.random.default_rng(1)
