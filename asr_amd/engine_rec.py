@@ -118,12 +118,13 @@ class RecPair(object):
             if d >= self.ndir:
                 out[nm] = None
                 continue
-            out[nm] = dict(kind='rec', args=dict(variant=dict(self.v), num_units=self.N, out_width=self.P,
-                                                grad_clipping=self.clip, backwards=self.reverse[d],
-                                                cls=self.cls, peepholes=self.peepholes, learn_init=self.learn_init,
-                                                only_return_final=self.only_return_final,
-                                                only_return_hidden=self.only_return_hidden),
-                           params=[r[0] for r in self.dirs[d].refmap])
+            args = dict(variant=dict(self.v), num_units=self.N, out_width=self.P, grad_clipping=self.clip,
+                        backwards=self.reverse[d], cls=self.cls)
+            for k, dflt in (('peepholes', False), ('learn_init', False), ('only_return_final', False),
+                            ('only_return_hidden', True)):       # options only when set: the frozen fixtures of
+                if getattr(self, k) != dflt:                     # tests/golden/ describe default layers without them
+                    args[k] = getattr(self, k)
+            out[nm] = dict(kind='rec', args=args, params=[r[0] for r in self.dirs[d].refmap])
         return out
 
     def get_sample_feat(self, d=0):

@@ -29,7 +29,7 @@ def pick(rng, xs):
 
 def make_case(rng):
     fam = pick(rng, ['lstm', 'lstm', 'ln_prj', 'ivec_cond', 'hyper', 'hyper', 'hyperlhuc', 'scaling', 'scaling_opt', 'prjhyper',
-                     'lhuc_ivec', 'rec', 'equalscale'])
+                     'lhuc_ivec', 'rec', 'rec_opt', 'equalscale'])
     D = int(rng.integers(1, 24)); C = int(rng.integers(2, 40))
     B = int(pick(rng, [1, 2, 3, 5, 15, 16, 17, 18, 31, 33, 40])); T = int(pick(rng, [1, 2, 3, 7, 19, 33, 64]))
     lengths = [int(rng.integers(1, T + 1)) for _ in range(B)]
@@ -77,7 +77,7 @@ def make_case(rng):
     elif fam == 'equalscale':
         Hs = [int(pick(rng, [4, 8, 16])) for _ in range(L)]
         Ns = [max(min(N, CAP) // 4 * 4, h) for h in Hs]
-        opt = dict(use_peepholes=bool(rng.integers(2)), use_layer_norm=bool(rng.integers(2)))
+        opt = dict(use_peepholes=bool(rng.integers(2)), use_layer_norm=bool(rng.integers(2)), learn_init=bool(rng.integers(2)))
         p.update(Hs=Hs, Ns=Ns, opt=opt)
         mk = lambda: G.deep_equal_scale_hyper_model(None, None, D, C, Hs, Ns, grad_clipping=clip, device=DEV, seed=1, **opt)
     elif fam == 'prjhyper':
@@ -87,6 +87,19 @@ def make_case(rng):
         I = 3
         mk = lambda: builders.build_deep_lhuclstm_ivector('ivector', None, None, D, L, N, 0, C, 1, 5, 0, 0, 0, I, clip, bidir,
                                                           False, False, I, True, device=DEV, seed=1)[0]
+    elif fam == 'rec_opt':      # the classes' options (recurrent_layers.py:52-57); only_return_final: tests/test_gpu_rec_options.py
+        cls = pick(rng, sorted(c for c in specs.REC_CLASSES if not specs.REC_CLASSES[c]['cond']))
+        N = min(N, CAP)
+        if N % 2:
+            N += 1
+        opt = dict(learn_init=bool(rng.integers(2)), only_return_hidden=bool(rng.integers(2)))
+        if cls in specs.REC_PEEPHOLE_CLASSES:
+            opt['peepholes'] = bool(rng.integers(2))
+        if not (opt['learn_init'] or opt.get('peepholes') or not opt['only_return_hidden']):
+            opt['learn_init'] = True
+        p.update(cls=cls, N=N, opt=opt)
+        mk = lambda: G._build_rec(D, C, L, N, clip, 0.0, cls, None, 0, num_factors=4, num_prjs=4, is_bidir=bidir, device=DEV,
+                                  seed=1, rec_options=opt)[0]
     else:
         cls = pick(rng, sorted(specs.REC_CLASSES)); v = specs.REC_CLASSES[cls]
         I = 3 if v['cond'] == 'ext' else 0
