@@ -211,6 +211,8 @@ def other_config(args, rank, world, dev):
     if args.precision:
         net.set_precision(args.precision)       # 'bf16' is refused for the layer-norm stacks (cfg2, cfg4); 'bf16x2' is not
     ar = dp.GradAllReduce(net)
+    if os.environ.get('ASR_DP_OVERLAP') is None:
+        ar.disable_overlap()                    # as for cfg3 (main): one collective after the last BPTT scan by default
     batches = []
     for i in range(args.pool):
         b = workloads.make_batch(cfg, BATCH, seed_offset=1000 * rank + i)
@@ -345,8 +347,13 @@ def main():
         raise SystemExit('bench.py: %d rows per GPU do not split into %d equal micro-batches' % (B_local, n_micro))
     if n_micro > 1:
         ar.suspend_overlap()        # the accumulated gradient is reduced once, after the last micro-batch
-    elif B_local > 16:
-        ar.disable_overlap()        # two teams per scan workgroup leave no registers for an RCCL wave (dp.py)
+    elif B_local > 16 or os.environ.get('ASR_DP_OVERLAP') is None:
+        # two teams per scan workgroup leave no registers for an RCCL wave (dp.py); and by default the bench reduces the
+        # gradient in ONE collective after the last BPTT scan: RCCL kernels beside a 256-workgroup persistent scan have
+        # never run on hardware (no multi-GPU node in any round), a collective that cannot get its CUs while a scan
+        # waits for co-residency would end in the scans' 10 s deadline on every rank, and what the overlap can hide is
+        # one all-reduce of 139 MB (~1 ms of a 175 ms step).  ASR_DP_OVERLAP=1 turns the bucketed overlap on.
+        ar.disable_overlap()
     batches = []
     sorted_lens = workloads.length_sorted_batches(3, B_local * world, args.pool) if args.length_sort else None
     t_local = []                                      # padded length of every pool batch on this rank
