@@ -245,13 +245,17 @@ __device__ __forceinline__ void combine_sums4(const float* st, int KS, int tid, 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int UT, int NC, bool OPT = false>
+// STREAM (layers too wide for resident weights: 16 UT N 4 bytes per workgroup above the CU's 160 KB, i.e. N > ~1280): the
+// A fragments are read from the packed image in global memory every step (L2 / Infinity Cache) instead of from LDS.
+// Same arithmetic in the same order; the step then streams N * 64 UT bytes per workgroup and is bandwidth-bound.
+template <int UT, int NC, bool OPT = false, bool STREAM = false>
 __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                   // [UT][KSP/4][64][4]
-    float* red = Wl + (size_t)UT * A.KSP * 64 + (threadIdx.x >> 8) * UT * 1024;   // per team [UT][4 waves][64][4]
-    int* flag = (int*)(Wl + (size_t)UT * A.KSP * 64 + NC * UT * 1024);
+    const size_t wfl = STREAM ? 0 : (size_t)UT * A.KSP * 64;                       // floats of resident weights
+    float* red = smem + wfl + (threadIdx.x >> 8) * UT * 1024;                      // per team [UT][4 waves][64][4]
+    int* flag = (int*)(smem + wfl + NC * UT * 1024);
 
     TEAM_IDS_(NC)
     const int q = lane >> 4, bl = lane & 15;
@@ -264,8 +268,9 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A)
     group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, A.G, j, flag);
 
     // resident weights
-    {
-        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * UT * KSP * 64);
+    const float* const Wg = D.wpack + (size_t)j * UT * KSP * 64;
+    if constexpr (!STREAM) {
+        const f32x4* src = (const f32x4*)Wg;
         f32x4* dst = (f32x4*)Wl;
         for (int i = threadIdx.x; i < UT * KSP * 16; i += 256 * NC) dst[i] = src[i];
     }
@@ -365,13 +370,25 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_kernel(LstmScanArgs A)
 #pragma unroll
             for (int i = 0; i < 8; ++i)    // tiles >= KS carry zero weights (and zeroed payload)
                 bv[i] = ldb_sc1_f4(rex_rs, ex_voff, (unsigned)(par * KSP * 256) + (unsigned)(wv * s4_per_wave + c0 + i) * 1024u);
+            f32x4 avs[STREAM ? 8 : 1][UT];                 // STREAM: the chunk's A fragments, requested together as well
+            if constexpr (STREAM) {
+#pragma unroll
+                for (int g4 = 0; g4 < 8; ++g4) {
+                    const int s4 = wave * s4_per_wave + (c0 + g4 < s4_per_wave ? c0 + g4 : s4_per_wave - 1);
+#pragma unroll
+                    for (int u = 0; u < UT; ++u)
+                        avs[g4][u] = *(const f32x4*)(Wg + (((size_t)u * (KSP / 4) + s4) * 64 + lane) * 4);
+                }
+            }
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
                 if (c0 + g4 < s4_per_wave) {
                     const int s4 = wave * s4_per_wave + c0 + g4;
 #pragma unroll
                     for (int u = 0; u < UT; ++u) {
-                        const f32x4 av = *(const f32x4*)(Wl + (((size_t)u * (KSP / 4) + s4) * 64 + lane) * 4);
+                        f32x4 av;
+                        if constexpr (STREAM) av = avs[g4][u];
+                        else av = *(const f32x4*)(Wl + (((size_t)u * (KSP / 4) + s4) * 64 + lane) * 4);
                         acc0[u] = mfma4(av[0], bv[g4][0], acc0[u]);
                         acc1[u] = mfma4(av[1], bv[g4][1], acc1[u]);
                         acc0[u] = mfma4(av[2], bv[g4][2], acc0[u]);
@@ -761,14 +778,15 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_fwd_cln_kernel(LstmScanArg
 //   2. cell / gate gradients for its units (+ LN backward with two small stat exchanges)
 //   3. partial dr_{t-1}[b, all k] = da[b, own cols] . W'[k, own cols]^T  -> publish per destination
 // ------------------------------------------------------------------------------------------------
-template <int UT, int NC, bool OPT = false>
+template <int UT, int NC, bool OPT = false, bool STREAM = false>
 __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A) {
     __builtin_amdgcn_s_setprio(3);       // latency-bound chain: win issue arbitration against co-resident GEMM waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wb = smem;                                   // [UT][KT][64][4]
-    float* dal = Wb + (size_t)UT * A.KT * 256 + (threadIdx.x >> 8) * UT * 1280;   // per team [UT][16 cols][16 b]
+    const size_t wfl = STREAM ? 0 : (size_t)UT * A.KT * 256;
+    float* dal = smem + wfl + (threadIdx.x >> 8) * UT * 1280;                      // per team [UT][16 cols][16 b]
     float* rsum = dal + UT * 256;                       // [UT][16 sg][16 b][4]
-    int* flag = (int*)(Wb + (size_t)UT * A.KT * 256 + NC * UT * 1280);
+    int* flag = (int*)(smem + wfl + NC * UT * 1280);
 
     TEAM_IDS_(NC)
     const int q = lane >> 4, bl = lane & 15;
@@ -778,8 +796,9 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A)
 
     GroupSync gs;
     group_sync_init(gs, A.sync + (size_t)sgrp * SYNC_STRIDE, A.G, j, flag);
-    {
-        const f32x4* src = (const f32x4*)(D.wpack + (size_t)j * UT * KT * 256);
+    const float* const Wg = D.wpack + (size_t)j * UT * KT * 256;
+    if constexpr (!STREAM) {
+        const f32x4* src = (const f32x4*)Wg;
         f32x4* dst = (f32x4*)Wb;
         for (int i = threadIdx.x; i < UT * KT * 64; i += 256 * NC) dst[i] = src[i];
     }
@@ -993,6 +1012,31 @@ __global__ __launch_bounds__(256 * NC) void lstm_scan_bwd_kernel(LstmScanArgs A)
         __syncthreads();
         STAMP(5);
         if (step + 1 < T) {
+            if constexpr (STREAM) {                      // 4 destination tiles' fragments requested together
+                for (int kt0 = wave; kt0 < KT; kt0 += 16) {
+                    f32x4 avs[4][UT];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int kt = kt0 + 4 * i < KT ? kt0 + 4 * i : kt0;
+#pragma unroll
+                        for (int u = 0; u < UT; ++u) avs[i][u] = *(const f32x4*)(Wg + (((size_t)u * KT + kt) * 64 + lane) * 4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int kt = kt0 + 4 * i;
+                        if (kt >= KT) continue;
+                        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                        for (int u = 0; u < UT; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc = mfma4(avs[i][u][e], dal[(size_t)u * 256 + (4 * e + q) * 16 + bl], acc);
+                        const int dst = kt * 4 + q;
+                        if (dst < KS)
+                            st_sc1_f4(dex_rs, (unsigned)(((((size_t)par * KS + dst) * G + j) * 64 + bl * 4) * 4), acc);
+                    }
+                }
+            } else
             for (int kt = wave; kt < KT; kt += 4) {
                 f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
@@ -1378,19 +1422,26 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
                            !d->dir[0].a0 && !(d->ndir > 1 && d->dir[1].a0) && !opt;
     const bool ln2d = backward && UT == 1 && !opt && asr_lstm_bwd_pack_mode(d->N, d->ndir, d->ln_kind) == 2;
     // LDS of a workgroup whose nc teams carry nc chunks: the resident weights once, the staging buffers per team
+    bool wstream = false;
     auto lds_of = [&](int nc) -> size_t {
         if (ln2d) return ((size_t)(A.KS / 32) * 2048 + (size_t)nc * 2304) * 4 + 64;
-        if (backward) return ((size_t)UT * A.KT * 256 + (size_t)nc * UT * 1280) * 4 + 64;
-        return ((size_t)UT * A.KSP * 64 + (size_t)nc * UT * 1024) * 4 + 64 + (fused_cln ? 1024 * nc : 0);
+        if (backward) return ((wstream ? 0 : (size_t)UT * A.KT * 256) + (size_t)nc * UT * 1280) * 4 + 64;
+        return ((wstream ? 0 : (size_t)UT * A.KSP * 64) + (size_t)nc * UT * 1024) * 4 + 64 + (fused_cln ? 1024 * nc : 0);
     };
-    if (lds_of(1) > 160 * 1024) return ASR_ERR_LIMIT;    // the resident weights do not fit a CU's LDS
+    if (lds_of(1) > 160 * 1024) {
+        // The resident weights do not fit a CU's LDS.  A bidirectional launch is refused (the caller runs the directions
+        // one by one: half the workgroups, possibly fewer tiles per workgroup, possibly resident again); a single
+        // direction streams its weights from L2 / Infinity Cache every step (UT >= 2 here; options: not instantiated)
+        if (d->ndir > 1 || opt || UT < 2) return ASR_ERR_LIMIT;
+        wstream = true;
+    }
     const int nc_cap = scan_nc_cap() >= 2 ? 2 : 1;
 
     for (int c0 = 0; c0 < nchunk_total;) {
         const int rem = nchunk_total - c0;
         // chunks that do not fit one launch as workgroups of their own (cpl z slices) ride as teams of two inside a
         // workgroup instead of waiting for a launch of their own
-        int nc = (rem > cpl && nc_cap >= 2 && !opt && lds_of(2) <= 160 * 1024) ? 2 : 1;
+        int nc = (rem > cpl && nc_cap >= 2 && !opt && !wstream && lds_of(2) <= 160 * 1024) ? 2 : 1;
         int nz = nc == 2 ? rem / 2 : rem;
         if (nz > cpl) nz = cpl;
         size_t lds = lds_of(nc);
@@ -1404,7 +1455,10 @@ static int lstm_scan_launch(const asr_lstm_scan_desc* d, void* ws, size_t ws_byt
         if (!scan_grid_fits((size_t)A.G * d->ndir * nz, lds)) return ASR_ERR_LIMIT;
         const void* fn = nullptr;
 #define PICK_NC_(...) (nc == 2 ? (const void*)__VA_ARGS__, 2> : (const void*)__VA_ARGS__, 1>)
-        if (opt) {
+        if (wstream) {
+            if (!backward) fn = UT == 2 ? (const void*)lstm_scan_fwd_kernel<2, 1, false, true> : (const void*)lstm_scan_fwd_kernel<4, 1, false, true>;
+            else fn = UT == 2 ? (const void*)lstm_scan_bwd_kernel<2, 1, false, true> : (const void*)lstm_scan_bwd_kernel<4, 1, false, true>;
+        } else if (opt) {
             if (!backward) fn = UT == 1 ? (const void*)lstm_scan_fwd_kernel<1, 1, true> : UT == 2 ? (const void*)lstm_scan_fwd_kernel<2, 1, true> : (const void*)lstm_scan_fwd_kernel<4, 1, true>;
             else fn = UT == 1 ? (const void*)lstm_scan_bwd_kernel<1, 1, true> : UT == 2 ? (const void*)lstm_scan_bwd_kernel<2, 1, true> : (const void*)lstm_scan_bwd_kernel<4, 1, true>;
         } else if (!backward) {

@@ -944,9 +944,11 @@ class Network(object):
                 self.scan_lstm(pair, one, backward, key=('lstm', pair.idx, backward, d))
             return
         if rc == -5:
-            raise _lib.AsrError('%s failed: ASR_ERR_LIMIT (-5): %d units are more than the '
-                                'resident-weight scan holds (16*UT*N*4 bytes of LDS per workgroup, UT in {1,2,4}, at most '
-                                '256 workgroups of N/(4*UT) per direction: about 1024 units)' % (what, desc.N))
+            raise _lib.AsrError('%s failed: ASR_ERR_LIMIT (-5): %d units are more than the persistent scan holds (at most '
+                                '256 co-resident workgroups of 4, 8 or 16 units per direction: 4096 units, a multiple of 16 '
+                                'above 2048; up to ~1280 units with the weights resident in LDS, streamed from L2 beyond; '
+                                'layers with peepholes / learn_init / cell_out only while the weights are resident)'
+                                % (what, desc.N))
         check(rc, what)
         self._last_groups = getattr(self, '_last_groups', {})
         self._last_groups[key] = desc.ndir * ((desc.B + 15) // 16)

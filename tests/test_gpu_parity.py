@@ -292,18 +292,33 @@ def test_hyperlstm_medium():
 
 def test_lstm_width_that_needs_one_launch_per_direction_and_the_width_limit():
     """516 units bidirectional: 129 workgroups per direction, 258 do not fit one launch and 516 is not a multiple of 8 (no
-    two-tile workgroups): Network.scan_lstm runs the directions one after the other.  2048 units: the weights alone are
-    more than the chip's LDS; the error says so."""
+    two-tile workgroups): Network.scan_lstm runs the directions one after the other.  4608 units: more than 256 workgroups
+    of 16 units; the error says so."""
     from asr_amd.builders import build_deep_lstm
     from asr_amd._lib import AsrError
     net = build_deep_lstm(None, None, 7, 2, 516, 0, 9, 1.0, True, True, 0, device=_dev(), seed=91)
     perturb_params(net, 92, 0.01)
     b = make_batch(np.random.default_rng(93), 3, 6, 7, 9)
     run_case(net, b, calibrate=True)
-    net = build_deep_lstm(None, None, 7, 1, 2048, 0, 9, 1.0, True, False, 0, device=_dev(), seed=94)
+    net = build_deep_lstm(None, None, 7, 1, 4608, 0, 9, 1.0, False, False, 0, device=_dev(), seed=94)
     x = torch.from_numpy(b['x']).to(net.device); m = torch.from_numpy(b['mask']).to(net.device)
-    with pytest.raises(AsrError, match='resident-weight scan holds'):
+    with pytest.raises(AsrError, match='more than the persistent scan holds'):
         net.posteriors(x, m, None)
+
+
+@pytest.mark.parametrize('kind,N,bidir', [('lstm', 1536, True), ('lstm', 2048, False), ('lstmp', 2048, True), ('ln', 1536, False),
+                                          ('lstm', 4096, False)])
+def test_lstm_wider_than_resident_weights_streams_them(kind, N, bidir):
+    """Layers whose recurrent weights do not fit a CU's LDS next to the staging buffers (16 UT N 4 bytes per workgroup:
+    above ~1280 units) run the generic scans with the weights streamed from L2 / Infinity Cache every step
+    (lstm_scan_{fwd,bwd}_kernel<UT, 1, false, true>; the reference has no width limit).  Plain, projected and
+    layer-normalised layers, one launch per direction, against the oracle."""
+    from asr_amd.builders import build_deep_lstm
+    pj = 256 if kind == 'lstmp' else 0
+    net = build_deep_lstm(None, None, 7, 1, N, pj, 9, 1.0, bidir, kind == 'ln', 0, device=_dev(), seed=95)
+    perturb_params(net, 96, 0.005)
+    b = make_batch(np.random.default_rng(97), 3, 5, 7, 9)
+    run_case(net, b, calibrate=True)
 
 
 def test_hyperlstm_wider_than_one_launch_holds():
