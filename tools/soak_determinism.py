@@ -51,6 +51,16 @@ cases = [
 cases += [('cfg3 32 rows (teams)', 3, cases[0][2], max(reps // 2, 4)), ('cfg2 32 rows (teams)', 2, cases[1][2], max(reps // 2, 4)),
           ('cfg4 32 rows (teams)', 4, cases[2][2], max(reps // 2, 4)),
           ('per-gate LN 32 rows (teams)', 2, cases[8][2], max(reps // 2, 4))]
+# round 3, second half: the option form of the generic scans (peepholes + learned initial rows + cell_out) and the
+# streamed-weight form (2048 units in one direction)
+cases += [('LSTMP options 2x512', 1, lambda: G._build_rec(123, 61, 2, 512, 1.0, 0.0, 'ProjectLSTMLayer', None, 0, num_factors=256,
+                                                          device=dev, seed=1, rec_options=dict(peepholes=True, learn_init=True,
+                                                                                               only_return_hidden=False))[0], reps),
+          ('LN-LSTMP learn_init 2x512', 1, lambda: G._build_rec(123, 61, 2, 512, 1.0, 0.0, 'LayerNormProjectLSTMLayer', None, 0,
+                                                                num_factors=256, device=dev, seed=1,
+                                                                rec_options=dict(learn_init=True))[0], reps),
+          ('LSTM 1x2048 streamed', 1, lambda: builders.build_deep_lstm(None, None, 123, 1, 2048, 0, 61, 1.0, False, False, 0,
+                                                                       device=dev, seed=1), max(reps // 2, 4))]
 bad = 0
 for name, cfg, mk, n in cases:
     net = mk()
