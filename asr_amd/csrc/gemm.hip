@@ -7,6 +7,7 @@
 // LDS images are k-major (As[k][m], Bs[k][n]) so that every MFMA operand read is a conflict-free
 // ds_read_b32 of 32 consecutive floats per lane half; double-buffered.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -573,6 +574,282 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
         }
 }
 
+// The same products as gemm_split_kernel from a workgroup of EIGHT waves on the same 128 x 128 x 16 tiles (wave = 64 x 32 of
+// the output): half the staging work and half the accumulators per wave, 128 registers per wave, so two workgroups per
+// CU are four waves per SIMD instead of two, and a wave's load / split / barrier phases have three other waves' matrix
+// phases to hide under.  Products, their order and the K-tile sign alternation are the same: results are bit-identical
+// to gemm_split_kernel's.  No pre-split operands.
+template <bool TA, bool TB, int TERMS>
+__global__ __launch_bounds__(512, 4) void gemm_split8_kernel(int M, int N, int K, float alpha,
+                                                          const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb,
+                                                          float beta, float* __restrict__ C, int ldc,
+                                                          const float* __restrict__ bias, int ntn,
+                                                          int kchunk, float* __restrict__ part, size_t plA, size_t plB) {
+    constexpr int NP = TERMS == 1 ? 1 : TERMS == 3 ? 2 : 3;
+    constexpr bool PA = false, PB = false;
+    constexpr bool AKM = TA, BKM = !TB;        // operand stored [k][row] (row contiguous)
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][NP][SPL_IMG];   // [buf][A|B][part]
+
+    int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        int q = nblk / 8, r = nblk % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 1; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    f32x4 ra[1], rb[1];
+    u32x4s qa[NP], qb[NP];                                 // pre-split operands: 8 bf16 per thread and part
+    const bool vecA = ((((uintptr_t)A) & 15) == 0) && ((lda & (PA ? 7 : 3)) == 0);
+    const bool vecB = ((((uintptr_t)B) & 15) == 0) && ((ldb & (PB ? 7 : 3)) == 0);
+    // pre-split operand, stored [k][row] (kmaj): thread -> k = tid / 16, rows 8 (tid % 16) ..;  stored [row][k]: row =
+    // tid / 2, k = 8 (tid % 2) ..  Columns between the matrix and its padded width hold zeros.
+    auto load_pre = [&](u32x4s* q, const float* X, int ld, size_t pl, bool kmaj, int k0, int r0, int nrows, int kdim,
+                        bool fast) {
+        const unsigned short* P = (const unsigned short*)X;
+        const int rr = kmaj ? k0 + (tid >> 4) : r0 + (tid >> 1);
+        const int cc = kmaj ? r0 + (tid & 15) * 8 : k0 + (tid & 1) * 8;
+        const bool ok = fast || (kmaj ? (rr < kdim && cc < ld) : (rr < nrows && cc < ld && cc < kdim));
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            q[p] = ok ? *(const u32x4s*)(P + (size_t)p * pl + (size_t)rr * ld + cc) : u32x4s{0, 0, 0, 0};
+    };
+    auto store_pre = [&](unsigned char (*img)[SPL_IMG], const u32x4s* q, bool kmaj, bool neg) {
+        const size_t off = kmaj ? (size_t)(tid >> 4) * SPL_KROW + (tid & 15) * 16
+                                : (size_t)(tid & 1) * SPL_KHALF + (tid >> 1) * 16;
+        const unsigned flip = neg ? 0x80008000u : 0u;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *(u32x4s*)(img[p] + off) = q[p] ^ flip;
+    };
+    auto ld4 = [&](const float* X, int ld, int r, int c, int R, int Cc, bool vec) -> f32x4 {
+        if (vec && r < R && c + 3 < Cc) return *(const f32x4*)(X + (size_t)r * ld + c);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (c + i < Cc) v[i] = X[(size_t)r * ld + c + i];
+        }
+        return v;
+    };
+    // thread -> elements.  [k][row] storage: k row kp = tid / 32, 4 columns at 4 (tid % 32).
+    //                      [row][k] storage: row tid / 4, 4 k at 4 (tid % 4).   (512 threads: one 16-byte piece each)
+    const int kp = tid >> 5, c4 = (tid & 31) * 4;
+    // interior tiles: per-thread pointers that walk along K (set behind `kbeg` below), so that an iteration's loads
+    // cost no 64-bit address arithmetic (in-kernel stamps: 359 of an iteration's 3900 cycles went into forming them)
+    const float* wa[2]; const float* wb[2];
+    const unsigned short* wpa = nullptr; const unsigned short* wpb = nullptr;
+    size_t stepA = 0, stepB = 0;
+    auto walk_init = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 1; ++e) {
+            const int idx = tid;
+            wa[e] = AKM ? A + (size_t)(k0 + kp) * lda + m0 + c4 : A + (size_t)(m0 + idx / 4) * lda + k0 + (idx % 4) * 4;
+            wb[e] = BKM ? B + (size_t)(k0 + kp) * ldb + n0 + c4 : B + (size_t)(n0 + idx / 4) * ldb + k0 + (idx % 4) * 4;
+        }
+        if (PA) wpa = (const unsigned short*)A + (AKM ? (size_t)(k0 + (tid >> 4)) * lda + m0 + (tid & 15) * 8
+                                                      : (size_t)(m0 + (tid >> 1)) * lda + k0 + (tid & 1) * 8);
+        if (PB) wpb = (const unsigned short*)B + (BKM ? (size_t)(k0 + (tid >> 4)) * ldb + n0 + (tid & 15) * 8
+                                                      : (size_t)(n0 + (tid >> 1)) * ldb + k0 + (tid & 1) * 8);
+        stepA = AKM ? (size_t)BK * lda : BK;
+        stepB = BKM ? (size_t)BK * ldb : BK;
+    };
+    auto load_tiles_fast = [&](f32x4* ra, f32x4* rb) {      // loads the tile the pointers stand on, then steps them
+        if (PA) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qa[p] = *(const u32x4s*)(wpa + (size_t)p * plA);
+            wpa += stepA;
+        }
+        if (PB) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qb[p] = *(const u32x4s*)(wpb + (size_t)p * plB);
+            wpb += stepB;
+        }
+#pragma unroll
+        for (int e = 0; e < 1; ++e) {
+            if (!PA) { ra[e] = *(const f32x4*)wa[e]; wa[e] += stepA; }
+            if (!PB) { rb[e] = *(const f32x4*)wb[e]; wb[e] += stepB; }
+        }
+    };
+    auto load_tiles = [&](int k0) {
+        if (PA) load_pre(qa, A, lda, plA, AKM, k0, m0, M, K, false);
+        if (PB) load_pre(qb, B, ldb, plB, BKM, k0, n0, N, K, false);
+#pragma unroll
+        for (int e = 0; e < 1; ++e) {
+            const int idx = tid;
+            if (!PA) {
+                if (AKM) ra[e] = ld4(A, lda, k0 + kp, m0 + c4, K, M, vecA);
+                else     ra[e] = ld4(A, lda, m0 + idx / 4, k0 + (idx % 4) * 4, M, K, vecA);
+            }
+            if (!PB) {
+                if (BKM) rb[e] = ld4(B, ldb, k0 + kp, n0 + c4, K, N, vecB);
+                else     rb[e] = ld4(B, ldb, n0 + idx / 4, k0 + (idx % 4) * 4, N, K, vecB);
+            }
+        }
+    };
+    auto store_op = [&](unsigned char (*img)[SPL_IMG], const f32x4* r, bool kmaj, float sg) {
+#pragma unroll
+        for (int e = 0; e < 1; ++e) {
+            unsigned w0[3], w1[3];
+            split_pair<NP>(r[e][0] * sg, r[e][1] * sg, w0);
+            split_pair<NP>(r[e][2] * sg, r[e][3] * sg, w1);
+            const int idx = tid;
+            // [k][row] storage: 4 rows c4.. of k = 2 kp + e;   [row][k] storage: row idx / 4, k = 4 (idx % 4) ..
+            const size_t off = kmaj ? (size_t)(kp) * SPL_KROW + c4 * 2
+                                    : (size_t)(((idx % 4) * 4) >> 3) * SPL_KHALF + (idx / 4) * 16 + (((idx % 4) * 4) & 7) * 2;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *(u32x2*)(img[p] + off) = u32x2{w0[p], w1[p]};
+        }
+    };
+    // K-tile t enters with the sign (-1)^t on its A operand and is joined with the same sign: see mfma_tile
+    auto sgn = [](int t) { return (TERMS > 1 && (t & 1)) ? -1.0f : 1.0f; };
+    auto store_tiles = [&](int t) {
+        if (PA) store_pre(sm[t & 1][0], qa, AKM, TERMS > 1 && (t & 1));
+        else store_op(sm[t & 1][0], ra, AKM, sgn(t));
+        if (PB) store_pre(sm[t & 1][1], qb, BKM, false);
+        else store_op(sm[t & 1][1], rb, BKM, 1.0f);
+    };
+    const int lr = lane & 31, lk = lane >> 5;
+    // transposed read: lane 4q + p of a 16-lane group addresses k row q, rows 4p .. 4p + 3 of the group's 16 rows
+    // and receives, for row (lane & 15) of the group, the 4 k of the block (cdna_hip_programming.md T10)
+    const int tr_off = (8 * lk + ((lane >> 2) & 3)) * SPL_KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto frag = [&](const unsigned char* img, int row0, bool kmaj) -> bf16x8 {
+        if (kmaj) {
+            typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+            const unsigned char* p = img + tr_off + row0 * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * SPL_KROW));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        return *(const bf16x8*)(img + (size_t)lk * SPL_KHALF + (row0 + lr) * 16);
+    };
+#define SPL_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc_, 0, 0, 0)
+    auto mfma_tile = [&](int tile) {
+        const int buf = tile & 1;
+        const float sg = sgn(tile);
+        bf16x8 a[2][NP], b[1][NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i][p] = frag(sm[buf][0][p], wm * 64 + i * 32, AKM);
+            b[0][p] = frag(sm[buf][1][p], wn * 32, BKM);
+        }
+        if (TERMS == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 1; ++j) SPL_MFMA(acc[i][j], a[i][0], b[j][0]);
+        } else {
+            // The bf16 MFMA truncates its fp32 accumulation toward -inf (measured: mean error -0.5 ulp of the accumulator
+            // per instruction, where v_mfma_f32_32x32x2_f32 rounds to nearest); a bias of one sign survives an LSTM's
+            // cell integration far better than rounding noise.  So the TERMS products of a K-tile form a chain from a
+            // zero accumulator and join the running sum with a round-to-nearest v_fma_f32, and K-tiles alternate in
+            // sign: odd tiles multiply -A (the split of -x is exactly minus the split of x) and are subtracted, so the
+            // truncation pushes the sum down on even tiles and up on odd ones and cancels in expectation.  (Accumulating
+            // straight into the running sum and flipping ITS sign every 4 tiles instead saves the 64 joins per tile: rms
+            // error 1.7e-7 instead of 8.6e-8, bias -3e-9, 2.5 % faster: not taken.)
+            constexpr int pa[8] = {0, 0, 1, 1, 0, 2, 1, 2}, pb[8] = {0, 1, 0, 1, 2, 0, 2, 1};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 1; ++j) {
+                    f32x16 tmp;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tmp[e] = 0.0f;
+#pragma unroll
+#if defined(SPL_ABL) && SPL_ABL == 2
+                    for (int t = TERMS - 1; t >= 0; --t) SPL_MFMA(acc[i][j], a[i][pa[t] < NP ? pa[t] : 0], b[j][pb[t] < NP ? pb[t] : 0]);
+                    continue;
+#endif
+#if defined(SPL_ABL) && SPL_ABL == 3
+                    for (int t = 2; t >= 0; --t) SPL_MFMA(tmp, a[i][t], b[j][t]);
+#else
+                    for (int t = TERMS - 1; t >= 0; --t) SPL_MFMA(tmp, a[i][pa[t] < NP ? pa[t] : 0], b[j][pb[t] < NP ? pb[t] : 0]);
+#endif
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(tmp[e], sg, acc[i][j][e]);
+                }
+        }
+    };
+#undef SPL_MFMA
+
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int Ksave = K;
+    K = kend;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nk_full = (kend - kbeg) / BK;
+    const bool interior = vecA && vecB && (m0 + BM <= M) && (n0 + BN <= N) && nk_full > 0;
+    if (interior) {
+        walk_init(kbeg);
+        load_tiles_fast(ra, rb);
+        store_tiles(0);
+        __syncthreads();
+        // one iteration per trip, not unrolled: an unrolled pair made the register allocator move the 64 accumulator
+        // registers between the halves (v_mov behind the MFMA latency).  Loads two tiles ahead and an MFMA / split-VALU
+        // interleave (sched_group_barrier) were measured and changed nothing: 162 vs 170 TFLOP/s
+#pragma unroll 1
+        for (int kt = 0; kt + 1 < nk_full; ++kt) {
+            load_tiles_fast(ra, rb);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(kt);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tiles(kt + 1);
+            __syncthreads();
+        }
+        if (nk > nk_full) {                                 // K tail: one guarded tile
+            load_tiles(kbeg + nk_full * BK);
+            mfma_tile(nk_full - 1);
+            store_tiles(nk_full);
+            __syncthreads();
+            mfma_tile(nk_full);
+        } else {
+            mfma_tile(nk_full - 1);
+        }
+    } else {
+        load_tiles(kbeg);
+        store_tiles(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+            mfma_tile(kt);
+            if (kt + 1 < nk) store_tiles(kt + 1);
+            __syncthreads();
+        }
+    }
+    K = Ksave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 1; ++j) {
+            const int col = n0 + wn * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = (bias && !part) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                const float s = acc[i][j][e];
+                if (part) { part[((size_t)blockIdx.y * M + row) * N + col] = s; continue; }
+                float* p = C + (size_t)row * ldc + col;
+                float v = alpha * s + bv;
+                if (beta != 0.0f) v += beta * (*p);
+                *p = v;
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ns,
                                                                   int M, int N, float alpha, float beta,
                                                                   float* __restrict__ C, int ldc,
@@ -633,6 +910,35 @@ static int gemm_launch(int mode, int transA, int transB, int M, int N, int K, fl
     }
     float* part = ns > 1 ? ws : nullptr;
     dim3 grid(tiles, ns), block(256);
+    static int wg8 = -1;                  // ASR_GEMM8=0: the four-wave kernel for every product (comparison runs)
+    if (wg8 < 0) { const char* e = getenv("ASR_GEMM8"); wg8 = e ? atoi(e) : 1; }
+    if (wg8 && !preA && !preB && (mode == 6 || mode == 3 || mode == 1)) {
+        dim3 block8(512);
+#define SPLIT8_(TA_, TB_, T_)                                                                            \
+        hipLaunchKernelGGL((gemm_split8_kernel<TA_, TB_, T_>), grid, block8, 0, stream, M, N, K, alpha, A, lda, B, ldb, \
+                           beta, C, ldc, bias, ntn, kchunk, part, plA, plB)
+#define LAUNCH8(TA_, TB_)                                                                                \
+        do {                                                                                            \
+            if (mode == 6) SPLIT8_(TA_, TB_, 6);                                                        \
+            else if (mode == 3) SPLIT8_(TA_, TB_, 3);                                                   \
+            else SPLIT8_(TA_, TB_, 1);                                                                  \
+        } while (0)
+        if (!transA && !transB) LAUNCH8(false, false);
+        else if (!transA && transB) LAUNCH8(false, true);
+        else if (transA && !transB) LAUNCH8(true, false);
+        else LAUNCH8(true, true);
+#undef LAUNCH8
+#undef SPLIT8_
+        ASR_CHECK_LAUNCH();
+        if (ns > 1) {
+            const size_t tot = (size_t)M * N;
+            const int g = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, stream, part, ns, M, N, alpha,
+                               beta, C, ldc, bias);
+            ASR_CHECK_LAUNCH();
+        }
+        return ASR_OK;
+    }
 #define SPLIT_(TA_, TB_, T_, PA_, PB_)                                                                   \
     hipLaunchKernelGGL((gemm_split_kernel<TA_, TB_, T_, PA_, PB_>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, \
                        ldb, beta, C, ldc, bias, ntn, kchunk, part, plA, plB)
