@@ -850,192 +850,6 @@ __global__ __launch_bounds__(512, 4) void gemm_split8_kernel(int M, int N, int K
         }
 }
 
-// Producer / consumer form of the same products (one workgroup of SIXTEEN waves per CU on a 128 x 128 x 16 tile): waves
-// 0-7 only multiply (64 x 32 of the output each: fragment reads, the chain of TERMS MFMAs, the round-to-nearest joins), waves
-// 8-15 only stage (global loads one K-tile ahead in registers, split, LDS stores of the next tile).  One barrier per K-tile.
-// A consumer wave never waits for a global load or spends its issue slots on the split; two consumer and two producer waves
-// share a SIMD.  Same products in the same order: bit-identical to gemm_split_kernel.
-template <bool TA, bool TB, int TERMS>
-__global__ __launch_bounds__(1024, 4) void gemm_split_pc_kernel(int M, int N, int K, float alpha,
-                                                             const float* __restrict__ A, int lda,
-                                                             const float* __restrict__ B, int ldb,
-                                                             float beta, float* __restrict__ C, int ldc,
-                                                             const float* __restrict__ bias, int ntn,
-                                                             int kchunk, float* __restrict__ part) {
-    constexpr int NP = TERMS == 1 ? 1 : TERMS == 3 ? 2 : 3;
-    constexpr bool AKM = TA, BKM = !TB;        // operand stored [k][row] (row contiguous)
-    __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][NP][SPL_IMG];   // [buf][A|B][part]
-
-    int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        int q = nblk / 8, r = nblk % 8, x = bid % 8;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-    }
-    const int tm = bid / ntn, tn = bid % ntn;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kbeg = blockIdx.y * kchunk;
-    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-    const int nk_full = kend > kbeg ? (kend - kbeg) / BK : 0;
-    auto sgn = [](int t) { return (TERMS > 1 && (t & 1)) ? -1.0f : 1.0f; };
-
-    if (wave < 8) {
-        // ---------------------------------------------------------------- consumers
-        const int wm = wave >> 2, wn = wave & 3;
-        f32x16 acc[2][1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.0f;
-        const int lr = lane & 31, lk = lane >> 5;
-        // transposed read: lane 4q + p of a 16-lane group addresses k row q, rows 4p .. 4p + 3 of the group's 16 rows
-        // and receives, for row (lane & 15) of the group, the 4 k of the block (cdna_hip_programming.md T10)
-        const int tr_off = (8 * lk + ((lane >> 2) & 3)) * SPL_KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-        auto frag = [&](const unsigned char* img, int row0, bool kmaj) -> bf16x8 {
-            if (kmaj) {
-                typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-                const unsigned char* p = img + tr_off + row0 * 2;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p);
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * SPL_KROW));
-                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-            return *(const bf16x8*)(img + (size_t)lk * SPL_KHALF + (row0 + lr) * 16);
-        };
-#define SPL_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc_, 0, 0, 0)
-        auto mfma_tile = [&](int tile) {
-            const int buf = tile & 1;
-            const float sg = sgn(tile);
-            bf16x8 a[2][NP], b[1][NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i][p] = frag(sm[buf][0][p], wm * 64 + i * 32, AKM);
-                b[0][p] = frag(sm[buf][1][p], wn * 32, BKM);
-            }
-            if (TERMS == 1) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 1; ++j) SPL_MFMA(acc[i][j], a[i][0], b[j][0]);
-            } else {
-                // The bf16 MFMA truncates its fp32 accumulation toward -inf (measured: mean error -0.5 ulp of the accumulator
-                // per instruction, where v_mfma_f32_32x32x2_f32 rounds to nearest); a bias of one sign survives an LSTM's
-                // cell integration far better than rounding noise.  So the TERMS products of a K-tile form a chain from a
-                // zero accumulator and join the running sum with a round-to-nearest v_fma_f32, and K-tiles alternate in
-                // sign: odd tiles multiply -A (the split of -x is exactly minus the split of x) and are subtracted, so the
-                // truncation pushes the sum down on even tiles and up on odd ones and cancels in expectation.  (Accumulating
-                // straight into the running sum and flipping ITS sign every 4 tiles instead saves the 64 joins per tile: rms
-                // error 1.7e-7 instead of 8.6e-8, bias -3e-9, 2.5 % faster: not taken.)
-                constexpr int pa[8] = {0, 0, 1, 1, 0, 2, 1, 2}, pb[8] = {0, 1, 0, 1, 2, 0, 2, 1};
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 1; ++j) {
-                        f32x16 tmp;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) tmp[e] = 0.0f;
-#pragma unroll
-#if defined(SPL_ABL) && SPL_ABL == 2
-                        for (int t = TERMS - 1; t >= 0; --t) SPL_MFMA(acc[i][j], a[i][pa[t] < NP ? pa[t] : 0], b[j][pb[t] < NP ? pb[t] : 0]);
-                        continue;
-#endif
-#if defined(SPL_ABL) && SPL_ABL == 3
-                        for (int t = 2; t >= 0; --t) SPL_MFMA(tmp, a[i][t], b[j][t]);
-#else
-                        for (int t = TERMS - 1; t >= 0; --t) SPL_MFMA(tmp, a[i][pa[t] < NP ? pa[t] : 0], b[j][pb[t] < NP ? pb[t] : 0]);
-#endif
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(tmp[e], sg, acc[i][j][e]);
-                    }
-            }
-        };
-#undef SPL_MFMA
-
-        __syncthreads();                                    // tile 0 is in LDS
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            mfma_tile(kt);
-            __syncthreads();                                // tile kt + 1 stored, tile kt's buffer free
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-    #pragma unroll
-            for (int j = 0; j < 1; ++j) {
-                const int col = n0 + wn * 32 + (lane & 31);
-                if (col >= N) continue;
-                const float bv = (bias && !part) ? bias[col] : 0.0f;
-    #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (row >= M) continue;
-                    const float s = acc[i][j][e];
-                    if (part) { part[((size_t)blockIdx.y * M + row) * N + col] = s; continue; }
-                    float* p = C + (size_t)row * ldc + col;
-                    float v = alpha * s + bv;
-                    if (beta != 0.0f) v += beta * (*p);
-                    *p = v;
-                }
-            }
-    
-    } else {
-        // ---------------------------------------------------------------- producers
-        const int tid = threadIdx.x - 512;
-        const int Kg = kend;                                // guarded loads see the K range of this split only
-        const bool vecA = ((((uintptr_t)A) & 15) == 0) && ((lda & 3) == 0);
-        const bool vecB = ((((uintptr_t)B) & 15) == 0) && ((ldb & 3) == 0);
-        const bool interior = vecA && vecB && (m0 + BM <= M) && (n0 + BN <= N);
-        auto ld4 = [&](const float* X, int ld, int r, int c, int R, int Cc, bool vec) -> f32x4 {
-            if (vec && r < R && c + 3 < Cc) return *(const f32x4*)(X + (size_t)r * ld + c);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < R) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) if (c + i < Cc) v[i] = X[(size_t)r * ld + c + i];
-            }
-            return v;
-        };
-        // thread -> elements.  [k][row] storage: k row kp = tid / 32, 4 columns at 4 (tid % 32);  [row][k] storage: row
-        // tid / 4, 4 k at 4 (tid % 4): one 16-byte piece of each operand per thread and K-tile
-        const int kp = tid >> 5, c4 = (tid & 31) * 4;
-        const float* wa = AKM ? A + (size_t)(kbeg + kp) * lda + m0 + c4 : A + (size_t)(m0 + tid / 4) * lda + kbeg + (tid % 4) * 4;
-        const float* wb = BKM ? B + (size_t)(kbeg + kp) * ldb + n0 + c4 : B + (size_t)(n0 + tid / 4) * ldb + kbeg + (tid % 4) * 4;
-        const size_t stepA = AKM ? (size_t)BK * lda : BK, stepB = BKM ? (size_t)BK * ldb : BK;
-        f32x4 ra, rb;
-        auto load_tile = [&](int kt) {
-            if (interior && kt < nk_full) {
-                ra = *(const f32x4*)(wa + (size_t)kt * stepA); rb = *(const f32x4*)(wb + (size_t)kt * stepB);
-            } else {
-                const int k0 = kbeg + kt * BK;
-                ra = AKM ? ld4(A, lda, k0 + kp, m0 + c4, Kg, M, vecA) : ld4(A, lda, m0 + tid / 4, k0 + (tid % 4) * 4, M, Kg, vecA);
-                rb = BKM ? ld4(B, ldb, k0 + kp, n0 + c4, Kg, N, vecB) : ld4(B, ldb, n0 + tid / 4, k0 + (tid % 4) * 4, N, Kg, vecB);
-            }
-        };
-        auto store_op = [&](unsigned char (*img)[SPL_IMG], const f32x4& r, bool kmaj, float sg) {
-            unsigned w0[3], w1[3];
-            split_pair<NP>(r[0] * sg, r[1] * sg, w0);
-            split_pair<NP>(r[2] * sg, r[3] * sg, w1);
-            const size_t off = kmaj ? (size_t)kp * SPL_KROW + c4 * 2
-                                    : (size_t)(((tid % 4) * 4) >> 3) * SPL_KHALF + (tid / 4) * 16 + (((tid % 4) * 4) & 7) * 2;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) *(u32x2*)(img[p] + off) = u32x2{w0[p], w1[p]};
-        };
-        auto store_tile = [&](int t) {
-            store_op(sm[t & 1][0], ra, AKM, sgn(t));
-            store_op(sm[t & 1][1], rb, BKM, 1.0f);
-        };
-        if (nk > 0) { load_tile(0); store_tile(0); }
-        if (nk > 1) load_tile(1);
-        __syncthreads();
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) store_tile(kt + 1);            // the tile loaded during the previous iteration
-            if (kt + 2 < nk) load_tile(kt + 2);             // in flight under the next iteration
-            __syncthreads();
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int ns,
                                                                   int M, int N, float alpha, float beta,
                                                                   float* __restrict__ C, int ldc,
@@ -1098,35 +912,6 @@ static int gemm_launch(int mode, int transA, int transB, int M, int N, int K, fl
     dim3 grid(tiles, ns), block(256);
     static int wg8 = -1;                  // ASR_GEMM8=0: the four-wave kernel for every product (comparison runs)
     if (wg8 < 0) { const char* e = getenv("ASR_GEMM8"); wg8 = e ? atoi(e) : 1; }
-    static int wgpc = -1;                 // ASR_GEMM_PC=1: the producer / consumer kernel (sixteen waves)
-    if (wgpc < 0) { const char* e = getenv("ASR_GEMM_PC"); wgpc = e ? atoi(e) : 0; }
-    if (wgpc && !preA && !preB && (mode == 6 || mode == 3 || mode == 1)) {
-        dim3 blockp(1024);
-#define SPLITP_(TA_, TB_, T_)                                                                            \
-        hipLaunchKernelGGL((gemm_split_pc_kernel<TA_, TB_, T_>), grid, blockp, 0, stream, M, N, K, alpha, A, lda, B, ldb, \
-                           beta, C, ldc, bias, ntn, kchunk, part)
-#define LAUNCHP(TA_, TB_)                                                                                \
-        do {                                                                                            \
-            if (mode == 6) SPLITP_(TA_, TB_, 6);                                                        \
-            else if (mode == 3) SPLITP_(TA_, TB_, 3);                                                   \
-            else SPLITP_(TA_, TB_, 1);                                                                  \
-        } while (0)
-        if (!transA && !transB) LAUNCHP(false, false);
-        else if (!transA && transB) LAUNCHP(false, true);
-        else if (transA && !transB) LAUNCHP(true, false);
-        else LAUNCHP(true, true);
-#undef LAUNCHP
-#undef SPLITP_
-        ASR_CHECK_LAUNCH();
-        if (ns > 1) {
-            const size_t tot = (size_t)M * N;
-            const int g = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
-            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, stream, part, ns, M, N, alpha,
-                               beta, C, ldc, bias);
-            ASR_CHECK_LAUNCH();
-        }
-        return ASR_OK;
-    }
     if (wg8 && !preA && !preB && (mode == 6 || mode == 3 || mode == 1)) {
         dim3 block8(512);
 #define SPLIT8_(TA_, TB_, T_)                                                                            \
