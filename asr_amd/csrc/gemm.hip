@@ -801,11 +801,17 @@ __global__ __launch_bounds__(512, 4) void gemm_split8_kernel(int M, int N, int K
         // interleave (sched_group_barrier) were measured and changed nothing: 162 vs 170 TFLOP/s
 #pragma unroll 1
         for (int kt = 0; kt + 1 < nk_full; ++kt) {
+#if !defined(G8_ABL) || (G8_ABL != 1 && G8_ABL != 4)   /* G8_ABL: timing ablations of tools/ubench/gemm_ablate.sh, never a product build */
             load_tiles_fast(ra, rb);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if !defined(G8_ABL) || G8_ABL != 3
             mfma_tile(kt);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if !defined(G8_ABL) || (G8_ABL != 2 && G8_ABL != 4)
             store_tiles(kt + 1);
+#endif
             __syncthreads();
         }
         if (nk > nk_full) {                                 // K tail: one guarded tile
