@@ -741,6 +741,9 @@ __global__ __launch_bounds__(512, 4) void gemm_split8_kernel(int M, int N, int K
         bf16x8 a[2][NP], b[1][NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
+#if defined(G8_ABL) && G8_ABL == 6      /* timing ablation: a third of the fragment reads, no loads, no stores */
+            if (p > 0) { a[0][p] = a[0][0]; a[1][p] = a[1][0]; b[0][p] = b[0][0]; continue; }
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i][p] = frag(sm[buf][0][p], wm * 64 + i * 32, AKM);
             b[0][p] = frag(sm[buf][1][p], wn * 32, BKM);
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(512, 4) void gemm_split8_kernel(int M, int N, int K
         // interleave (sched_group_barrier) were measured and changed nothing: 162 vs 170 TFLOP/s
 #pragma unroll 1
         for (int kt = 0; kt + 1 < nk_full; ++kt) {
-#if !defined(G8_ABL) || (G8_ABL != 1 && G8_ABL != 4)   /* G8_ABL: timing ablations of tools/ubench/gemm_ablate.sh, never a product build */
+#if !defined(G8_ABL) || (G8_ABL != 1 && G8_ABL != 4 && G8_ABL != 6)   /* G8_ABL: timing ablations of tools/ubench/gemm_ablate.sh, never a product build */
             load_tiles_fast(ra, rb);
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(512, 4) void gemm_split8_kernel(int M, int N, int K
             mfma_tile(kt);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-#if !defined(G8_ABL) || (G8_ABL != 2 && G8_ABL != 4)
+#if !defined(G8_ABL) || (G8_ABL != 2 && G8_ABL != 4 && G8_ABL != 6)
             store_tiles(kt + 1);
 #endif
             __syncthreads();
