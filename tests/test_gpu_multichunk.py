@@ -120,3 +120,46 @@ def test_lstm_family_40_rows_full_width_vs_oracle(kind):
     perturb_params(net, 13, 0.02)
     b = make_batch(np.random.default_rng(77), 40, 12, 9, 11)
     run_case(net, b, calibrate=(kind != 'lstm'))
+
+
+@pytest.mark.parametrize('kind', ['hyper', 'ln_lstmp'])
+def test_micro_batches_accumulate_to_the_whole_batch_gradient(kind):
+    """bench.py's strong leg (--global-batch 128 on few GPUs): a rank's rows sorted by length, cut into micro-batches padded
+    to their own longest row, each pass scaled by 1 / (rows of all parts) (Network.world), gradients accumulated on the
+    device (Network.grad_accumulate): the sum is the gradient of the whole batch in one pass (fp32 summation order aside)
+    and matches the oracle on the whole batch."""
+    from asr_amd import builders, gating_hyper_nets as G
+    from oracle import asr_oracle as O
+    if kind == 'hyper':
+        net = builders.build_deep_hyperlstm('hyper', None, None, 9, 2, 32, 8, 4, 11, 1.0, True, 0, device=DEV, seed=15)
+    else:
+        net = G.deep_projection_ln_lstm_model(None, None, 9, 11, 2, None, 32, grad_clipping=1.0, dropout=0.0, device=DEV, seed=15)
+    perturb_params(net, 16, 0.05)
+    B, T, parts = 40, 21, 2
+    b = make_batch(np.random.default_rng(17), B, T, 9, 11)
+    x, m, y = _t(b['x']), _t(b['mask']), _t(b['y'])
+    ce_all, _, _ = net.loss(x, m, y, m)
+    net.backward(); net.check_status()
+    g_all = net.store.g.clone(); ce_all = ce_all.item()
+    order = np.argsort(-b['lengths'], kind='stable')
+    net.world = parts
+    ce_sum = 0.0
+    for k in range(parts):
+        rows = order[k * (B // parts):(k + 1) * (B // parts)]
+        Tk = int(b['lengths'][rows].max())
+        xs, ms, ys = (_t(b[n][rows, :Tk]) for n in ('x', 'mask', 'y'))
+        ce, _, _ = net.loss(xs, ms, ys, ms)
+        net.backward()
+        net.grad_accumulate(first=(k == 0))
+        ce_sum += ce.item()
+    net.grad_accumulated(); net.check_status()
+    net.world = 1
+    g_acc = net.store.g.clone()
+    assert abs(ce_sum - ce_all) <= 2e-5 * abs(ce_all)            # the frame sums add up
+    scale = g_all.abs().max().item()
+    assert (g_acc - g_all).abs().max().item() <= 2e-5 * scale, (g_acc - g_all).abs().max().item() / scale
+    onet = O.OracleNetwork(net.describe(), net.get_all_param_values())
+    _, _, _, og = onet.loss_and_grads(b['x'], b['mask'], b['y'], b['mask'])
+    gmax = max(np.abs(g).max() for g in og)
+    for (nm, _), g, o in zip(net.param_names_shapes(), net.get_all_grad_values(), og):
+        assert np.abs(g - o).max() / (np.abs(o).max() + 1e-3 * gmax) < 1e-4, nm

@@ -617,3 +617,27 @@ def test_eval_net_skip_scores_all_frames_with_repeated_predictions():
     pred_full = np.repeat(np.where(np.arange(4)[None] % 2 == 0, y[:, ::skip], (y[:, ::skip] + 1) % C), skip, axis=1)[:, :T]
     want = 1.0 - ((pred_full == y) * m).sum() / m.sum()
     assert abs(fer - want) < 1e-12
+
+
+def test_length_sorted_batches_are_slices_of_a_sorted_cache():
+    """workloads.length_sorted_batches (the reference's LengthSortTransformer, data/transformers.py:15-63): a cache of >= 1024
+    utterances is sorted by length and cut into consecutive batches; every utterance of a cache lands in exactly one batch."""
+    from asr_amd import workloads
+    B = 16
+    bs = workloads.length_sorted_batches(3, B, 64)
+    assert len(bs) == 64 and all(len(b) == B for b in bs)
+    cache = np.sort(np.concatenate(bs))                      # one cache = 1024 utterances = 64 batches of 16
+    again = workloads.length_sorted_batches(3, B, 64)
+    assert all((a == b).all() for a, b in zip(bs, again))    # seeded
+    for b in bs:
+        assert (np.diff(b) >= 0).all()                       # sorted inside a batch
+        i = np.searchsorted(cache, b[0], side='left')        # and a run of neighbours in the sorted cache
+        spread = b[-1] - b[0]
+        assert spread <= cache[min(i + 2 * B, len(cache) - 1)] - cache[i]
+    spreads = [int(b[-1] - b[0]) for b in bs]
+    rng = np.random.default_rng(0)
+    unsorted = [workloads.lengths_for(3, rng, B) for _ in range(64)]
+    assert np.mean(spreads) < 0.1 * np.mean([int(u.max() - u.min()) for u in unsorted])
+    # padded frames: sorted batches waste far less than random ones
+    waste = lambda L: 1.0 - sum(int(l.sum()) for l in L) / sum(int(l.max()) * len(l) for l in L)
+    assert waste(bs) < 0.05 < waste(unsorted)
