@@ -315,14 +315,37 @@ static int prj_target_wgs() {
     }
     return v;
 }
-static PrjSplits prj_splits(int B, int N, int ndir) {
-    const int tw = prj_target_wgs(), npz = ndir * ((B + 15) / 16);
+static int prj_persist_grid();
+#define PRJ_PERSIST_MAXN 512             // one unit per thread (wider cells spill beside the resident weights)
+// tw: workgroups a product's launch is split for
+static PrjSplits prj_splits_tw(int B, int N, int ndir, int tw) {
+    const int npz = ndir * ((B + 15) / 16);
     PrjSplits s;
     s.f = skinny_nsplit(false, N, 8 * N, npz, tw);        // the shorter of the two reduction ranges (zero block)
     s.w3 = skinny_nsplit(false, N, 12 * N, npz, tw);
     s.bf = skinny_nsplit(true, 4 * N, 2 * N, npz, tw);
     s.b3 = skinny_nsplit(true, 12 * N, N, npz, tw);
     return s;
+}
+// The persistent launch keeps every wave's slice of the weights on the chip (prj_persist_*_kernel): that needs ONE round
+// of weight loads per wave and at most one block per half-workgroup in each of the four products.
+static bool prj_resident(int B, int N, int ndir, const PrjSplits& s, int G) {
+    const int npz = ndir * ((B + 15) / 16);
+    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    const int nb_f = cdiv(8 * N, 64), nb_3 = cdiv(12 * N, 64), nb_b3 = cdiv(N, 16), nb_bf = cdiv(2 * N, 16);
+    return nb_f * s.f * npz <= 2 * G && nb_3 * s.w3 * npz <= 2 * G && nb_b3 * s.b3 * npz <= 2 * G && nb_bf * s.bf * npz <= 2 * G &&
+           cdiv(cdiv(2 * N, 4), 4 * s.f) <= 16 && cdiv(cdiv(N, 4), 4 * s.w3) <= 16 &&
+           cdiv(cdiv(12 * N, 64), 4 * s.b3) <= 4 && cdiv(cdiv(8 * N, 64), 4 * s.bf) <= 4;
+}
+// workgroups of the persistent launch for this shape (one per CU, two product blocks each), 0: step loop
+static int prj_use_persist(int B, int N, int ndir) {
+    const int g = N <= PRJ_PERSIST_MAXN ? prj_persist_grid() : 0;
+    if (!g || g < B * ndir) return 0;                     // every cell needs a workgroup of its own
+    return prj_resident(B, N, ndir, prj_splits_tw(B, N, ndir, 2 * g), g) ? g : 0;
+}
+static PrjSplits prj_splits(int B, int N, int ndir) {
+    const int pg = prj_use_persist(B, N, ndir);
+    return prj_splits_tw(B, N, ndir, pg ? 2 * pg : prj_target_wgs());
 }
 static size_t prj_part_floats(int B, int N, int ndir) {
     const PrjSplits s = prj_splits(B, N, ndir);
@@ -332,9 +355,16 @@ static size_t prj_part_floats(int B, int N, int ndir) {
     return (fw > bw ? fw : bw) * ndir;
 }
 
+// workspace: [sync block of the persistent launch (asr_scan_status(ws, 1) reads it) | carried d cell | partial blocks]
+#define PRJ_SYNC_BYTES ((size_t)((SYNC_STRIDE * 4 + 255) / 256) * 256)
+#ifdef SCAN_STAMPS
+#define PRJ_STAMP_BYTES STAMP_BYTES
+#else
+#define PRJ_STAMP_BYTES 0
+#endif
 extern "C" size_t asr_prjhyper_ws_bytes(int B, int N, int F, int ndir) {
     (void)F;
-    return ((size_t)2 * ndir * B * N + prj_part_floats(B, N, ndir)) * sizeof(float) + 256;
+    return PRJ_SYNC_BYTES + ((size_t)2 * ndir * B * N + prj_part_floats(B, N, ndir)) * sizeof(float) + 256 + PRJ_STAMP_BYTES;
 }
 
 static int prj_check(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes) {
@@ -344,6 +374,12 @@ static int prj_check(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes) {
         return ASR_ERR_ARG;
     if (ws_bytes < asr_prjhyper_ws_bytes(d->B, d->N, d->F, d->ndir)) return ASR_ERR_WS;
     return ASR_OK;
+}
+
+// in-kernel phase stamps of the persistent launch (diagnostic build only): the workspace tail
+static unsigned long long* prj_dbg(const asr_prjhyper_desc* d, void* ws) {
+    return PRJ_STAMP_BYTES ? (unsigned long long*)((char*)ws + asr_prjhyper_ws_bytes(d->B, d->N, d->F, d->ndir) - PRJ_STAMP_BYTES)
+                           : nullptr;
 }
 
 struct PrjHost {
@@ -358,7 +394,7 @@ static void prj_args(const asr_prjhyper_desc* d, void* ws, hipStream_t st, bool 
     A.b0 = d->b0; A.Btot = d->Btot;
     A.mask = d->mask; A.msb = d->mask_stride_b; A.mst = d->mask_stride_t;
     A.d[0] = d->dir[0]; A.d[1] = d->dir[d->ndir > 1 ? 1 : 0];
-    float* p = (float*)ws;
+    float* p = (float*)((char*)ws + PRJ_SYNC_BYTES);
     const int N = d->N;
     const size_t bn = (size_t)d->ndir * d->B * N;
     A.g_c[0] = p; p += bn; A.g_c[1] = p; p += bn;
@@ -406,6 +442,450 @@ static void prj_times(const asr_prjhyper_desc* d, PrjArgs& A, int step) {
     if (d->ndir == 1) { A.t[1] = A.t[0]; A.tp[1] = A.tp[0]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same steps as ONE persistent launch per pass: the four kernels of a step become four phases
+// of a loop inside one kernel, a kernel boundary (~5 us in this chain) becomes an exchange of scan_common.h (sc1 stores,
+// every storing wave drains, one arrival per workgroup on a sharded counter; consumers poll, then read with sc1 loads:
+// ~2.3 us).  One workgroup per CU (the sc1 hand-off is measured for that), as many as the chip has CUs; a phase's
+// blocks -- the (output block, split, direction x row chunk) triples of a skinny product, the (row, direction) pairs of
+// a cell -- are dealt round-robin to the workgroups.  The folded weights (50 MB at 512 units, both directions) are
+// streamed from L2 / Infinity Cache every step as before.  Results are those of the step loop bit for bit when the
+// splits are the same (same bodies, same summation order); the splits follow the grid, so they are the step loop's
+// only when ASR_SK_WGS equals the CU count.
+
+__device__ __forceinline__ void prj_sk_args(SkinnyArgs& S, const PrjArgs& A, const float* const Ain[2], int lda,
+                                            bool w3, int ldw, float* const Cp[2], int K, int Nc, int ns, int zfrom,
+                                            int zk0, int zk1, bool nt) {
+#pragma unroll
+    for (int k = 0; k < SK_MAXP; ++k) {
+        S.p[k].A = Ain[k]; S.p[k].W = w3 ? A.d[k].W3 : A.d[k].Wf; S.p[k].bias = nullptr; S.p[k].C = Cp[k];
+    }
+    S.lda = lda; S.ldw = ldw; S.ldc = Nc; S.Bm = A.B; S.K = K; S.Nc = Nc; S.beta = 0; S.nsplit = ns; S.raw = 1;
+    S.nchunk = (A.B + 15) / 16;
+    if (zfrom < 0) { S.zfrom = nt ? 0 : 0x7fffffff; S.zk0 = 0; S.zk1 = 0; }
+    else { S.zfrom = zfrom; S.zk0 = zk0; S.zk1 = zk1; }
+    S.part = nullptr; S.tickets = nullptr;
+}
+
+
+// Workgroups of 512 threads: a product phase runs two blocks side by side (threads 0-255 and 256-511: eight waves of
+// loads in flight per CU), a cell uses all 512 threads for its row.  Every phase has the shape
+//     loads that do not depend on the exchange before it  ->  wait for that exchange  ->  the dependent loads, the
+//     arithmetic, the stores that other workgroups read  ->  publish  ->  the stores only later kernels read
+// so the weights of a product stream in under the cell phase before it, a cell's inputs under the product before it, and
+// the saved tensors' stores (21 floats per unit and cell) drain under the phase after.
+#define PRJ_PT 512
+
+// The cells of prj_cell_fwd_kernel / prj_cell_bwd_kernel in that shape (same expressions, same order).
+template <int OUTER, int NU, class WaitF, class PubF>
+__device__ __forceinline__ bool prj_cell_fwd_pbody(const PrjArgs& A, int b, int dir, int t, int tp, float* sm, WaitF waitf,
+                                                   PubF pubf) {
+    const PrjDir& D = A.d[dir];
+    const int N = A.N;
+    const size_t row = (size_t)t * A.Btot + A.b0 + b, rowp = (size_t)(tp < 0 ? 0 : tp) * A.Btot + A.b0 + b;
+    const float m = A.mask[(size_t)(A.b0 + b) * A.msb + (size_t)t * A.mst];
+    const float* alpha = OUTER ? D.ao : D.ai;
+    const float* beta = OUTER ? D.bo_c : D.bi_c;
+    float* gsv = (OUTER ? D.go : D.gi) + row * 4 * N;
+    float* cst = OUTER ? D.co : D.ci;
+    float* rst = D.r + (OUTER ? N : 0);              // row stride 2N
+    int nn[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) nn[u] = min((int)threadIdx.x + u * PRJ_PT, N - 1);
+    float rec[NU][4], scv[NU][12], cp[NU], rpv[NU], xin[NU][4], al[NU], be[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {                   // ---- independent of the exchange
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rec[u][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) scv[u][k] = OUTER ? D.s[k * N + nn[u]] : 0.f;
+        cp[u] = ldx<true>(cst + rowp * N + nn[u]);                          // this workgroup's own stores of the step before
+        rpv[u] = ldx<true>(rst + rowp * 2 * N + nn[u]);
+        al[u] = alpha[nn[u]]; be[u] = beta[nn[u]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xin[u][k] = (OUTER ? D.outer_in : D.inner_in)[row * 4 * N + k * N + nn[u]];
+    }
+    if (!waitf()) return false;
+    if (tp >= 0) {                                   // ---- sums of the partial blocks
+        const float* pf = A.pf[dir] + (size_t)b * 8 * N + (OUTER ? 4 * N : 0);
+        PART_SUM_BEGIN(A.ns_f)
+            const float* pp = pf + (size_t)sp * A.Bpad * 8 * N;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rec[u][k] += pw * ldx<true>(pp + k * N + nn[u]);
+            }
+        PART_SUM_END
+    }
+    if (OUTER) {
+        const float* p3 = A.p3[dir] + (size_t)b * 12 * N;
+        PART_SUM_BEGIN(A.ns_3)
+            const float* pp = p3 + (size_t)sp * A.Bpad * 12 * N;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) scv[u][k] += pw * ldx<true>(pp + k * N + nn[u]);
+            }
+        PART_SUM_END
+    }
+    float cn[NU], g4[NU][4];
+    float s1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int n = threadIdx.x + u * PRJ_PT;
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            g[k] = OUTER ? xin[u][k] * scv[u][k] + rec[u][k] * scv[u][4 + k] + scv[u][8 + k]      // :375-377
+                         : xin[u][k] + rec[u][k];                                                   // :329-331
+        g4[u][0] = sigmoidf_(g[0]); g4[u][1] = sigmoidf_(g[1]); g4[u][2] = tanhf_(g[2]); g4[u][3] = sigmoidf_(g[3]);
+        if (tp < 0) cp[u] = 0.f;
+        cn[u] = g4[u][1] * cp[u] + g4[u][0] * g4[u][2];                // :355 | :401
+        if (n < N) s1 += cn[u];
+    }
+    const float mean = block_sum<PRJ_PT / 64>(s1, sm) / N;
+    float s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int n = threadIdx.x + u * PRJ_PT;
+        if (n < N) { const float dlt = cn[u] - mean; s2 += dlt * dlt; }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum<PRJ_PT / 64>(s2, sm) / N + ASR_EPS);   // ln :9-12
+    float xh[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int n = threadIdx.x + u * PRJ_PT;
+        xh[u] = (cn[u] - mean) * rstd;
+        const float r = g4[u][3] * tanhf_(al[u] * xh[u] + be[u]);      // :357-363 | :403-409
+        const float rp = tp < 0 ? 0.f : rpv[u];
+        if (n < N) {
+            stx<true>(cst + row * N + n, m != 0.f ? cn[u] : cp[u]);      // :441-444
+            stx<true>(rst + row * 2 * N + n, m != 0.f ? r : rp);
+        }
+    }
+    pubf();
+    if (threadIdx.x == 0) (OUTER ? D.rso : D.rsi)[row] = rstd;        // ---- read by later kernels only
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int n = threadIdx.x + u * PRJ_PT;
+        if (n < N) {
+            gsv[n] = g4[u][0]; gsv[N + n] = g4[u][1]; gsv[2 * N + n] = g4[u][2]; gsv[3 * N + n] = g4[u][3];
+            if (OUTER) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) D.a[row * 4 * N + k * N + n] = rec[u][k];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) D.sc[row * 12 * N + k * N + n] = scv[u][k];
+            }
+            (OUTER ? D.xho : D.xhi)[row * N + n] = xh[u];
+        }
+    }
+    return true;
+}
+
+template <int OUTER, int NU, class WaitF, class PubF>
+__device__ __forceinline__ bool prj_cell_bwd_pbody(const PrjArgs& A, int b, int dir, int t, int tp, bool first, float* sm,
+                                                   WaitF waitf, PubF pubf) {
+    const PrjDir& D = A.d[dir];
+    const int N = A.N;
+    const size_t row = (size_t)t * A.Btot + A.b0 + b, rowp = (size_t)(tp < 0 ? 0 : tp) * A.Btot + A.b0 + b;
+    const bool on = A.mask[(size_t)(A.b0 + b) * A.msb + (size_t)t * A.mst] != 0.f;
+    const float* alpha = OUTER ? D.ao : D.ai;
+    const float* beta = OUTER ? D.bo_c : D.bi_c;
+    const float* gsv = (OUTER ? D.go : D.gi) + row * 4 * N;
+    const float* cpv = (OUTER ? D.co : D.ci) + rowp * N;
+    const float* xhat = (OUTER ? D.xho : D.xhi) + row * N;
+    const float rstd = (OUTER ? D.rso : D.rsi)[row];
+    float* g_c = A.g_c[OUTER] + ((size_t)dir * A.B + b) * N;
+    const float* dr_t = D.dr + row * 2 * N + (OUTER ? N : 0);
+    float* dr_p = D.dr + rowp * 2 * N + (OUTER ? N : 0);
+    float* dout_sv = (OUTER ? D.douto : D.douti) + row * N;
+    const float* sc = D.sc + row * 12 * N;
+    const float* oin = D.outer_in + row * 4 * N;
+    const float* av = D.a + row * 4 * N;
+    float gr[NU], gcar[NU], xh[NU], al[NU], be[NU], g4[NU][4], cpr[NU], drp[NU];
+    float s_in[NU][4], s_ou[NU][4], x_in[NU][4], x_a[NU][4];
+    int nn[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {                   // ---- independent of the exchange
+        const int n = nn[u] = min((int)threadIdx.x + u * PRJ_PT, N - 1);
+        gr[u] = ldx<true>(dr_t + n); gcar[u] = ldx<true>(g_c + n); xh[u] = xhat[n]; al[u] = alpha[n]; be[u] = beta[n];
+        cpr[u] = cpv[n];
+        drp[u] = ldx<true>(dr_p + n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            g4[u][k] = gsv[k * N + n];
+            if (OUTER) {
+                s_in[u][k] = sc[k * N + n]; s_ou[u][k] = sc[4 * N + k * N + n];
+                x_in[u][k] = oin[k * N + n]; x_a[u][k] = av[k * N + n];
+            }
+        }
+    }
+    if (!waitf()) return false;
+    // total d r_t of this cell: + what the recurrent products hand over (their partial blocks)
+    if (!first) {
+        const float* pb = A.pbf[dir] + (size_t)b * 2 * N + (OUTER ? N : 0);
+        PART_SUM_BEGIN(A.ns_bf)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) gr[u] += pw * ldx<true>(pb + (size_t)sp * A.Bpad * 2 * N + nn[u]);
+        PART_SUM_END
+    }
+    if (!OUTER) {
+        const float* pb = A.pb3[dir] + (size_t)b * N;
+        PART_SUM_BEGIN(A.ns_b3)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) gr[u] += pw * ldx<true>(pb + (size_t)sp * A.Bpad * N + nn[u]);
+        PART_SUM_END
+    }
+    float dxh[NU], do_[NU], dout[NU];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int n = threadIdx.x + u * PRJ_PT;
+        const bool act = on && n < N;
+        const float tc = tanhf_(al[u] * xh[u] + be[u]);
+        do_[u] = act ? gr[u] * tc : 0.f;
+        dout[u] = act ? clipf_(gr[u] * g4[u][3] * (1.f - tc * tc), A.clip) : 0.f;    // :358-361 | :404-407
+        dxh[u] = dout[u] * al[u];
+        s1 += dxh[u]; s2 += dxh[u] * xh[u];
+    }
+    const float m1 = block_sum<PRJ_PT / 64>(s1, sm) / N;
+    const float m2 = block_sum<PRJ_PT / 64>(s2, sm) / N;
+    float dg[NU][4], gcn[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int n = threadIdx.x + u * PRJ_PT;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dg[u][k] = 0.f;
+        const float ig = g4[u][0], fg = g4[u][1], gc = g4[u][2], o = g4[u][3];
+        const float cprev = tp < 0 ? 0.f : cpr[u];
+        const float dct = gcar[u] + rstd * (dxh[u] - m1 - xh[u] * m2);
+        gcn[u] = dct * fg;
+        if (on) {
+            dg[u][0] = clipf_(dct * gc * ig * (1.f - ig), A.clip);
+            dg[u][1] = clipf_(dct * cprev * fg * (1.f - fg), A.clip);
+            dg[u][2] = clipf_(dct * ig * (1.f - gc * gc), A.clip);
+            dg[u][3] = clipf_(do_[u] * o * (1.f - o), A.clip);
+        }
+        if (n >= N) continue;                            // stores only below: what the products of this step read
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (OUTER) {
+                stx<true>(D.dta + row * 8 * N + 4 * N + k * N + n, dg[u][k] * s_ou[u][k]);     // d (outer_hid_prev.W)
+                float* ds = D.dsc + row * 12 * N;
+                stx<true>(ds + k * N + n, dg[u][k] * x_in[u][k]);
+                stx<true>(ds + 4 * N + k * N + n, dg[u][k] * x_a[u][k]);
+                stx<true>(ds + 8 * N + k * N + n, dg[u][k]);
+            } else {
+                stx<true>(D.dta + row * 8 * N + k * N + n, dg[u][k]);
+            }
+        }
+    }
+    pubf();
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {                   // ---- this workgroup's own carry, and what later kernels read
+        const int n = threadIdx.x + u * PRJ_PT;
+        if (n >= N) continue;
+        dout_sv[n] = dout[u];
+        if (on) stx<true>(g_c + n, gcn[u]);
+        else if (tp >= 0) stx<true>(dr_p + n, drp[u] + gr[u]);   // off: the state was copied, its gradient passes on
+        if (OUTER) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) D.doi[row * 4 * N + k * N + n] = dg[u][k] * s_in[u][k];     // d outer_input
+        }
+    }
+    return true;
+}
+
+#define PRJ_PERSIST_SETUP \
+    GroupSync gs; \
+    STAMP_DECL \
+    const int wg = blockIdx.x, G = gridDim.x; \
+    group_sync_init(gs, sync, G, wg, flag); \
+    bool pending = false;                    /* a publish whose wait is still to come (uniform over the grid) */ \
+    int ph = 0;                              /* phase of the step (diagnostic stamps: 4 per phase) */ \
+    auto waitf = [&]() -> bool { STAMP(4 * ph); if (!pending) return true; pending = false; const bool ok_ = group_wait(gs); \
+                                 STAMP(4 * ph + 1); return ok_; }; \
+    auto pubf = [&]() { STAMP(4 * ph + 2); group_publish(gs); pending = true; STAMP(4 * ph + 3); };
+
+// LDS of the persistent kernels: [8 waves][16][64] f32x4 = 128 KB (each wave's slice of W3) | partial sums of the
+// waves of a product block: 2 halves x 3 waves x 4 KB (forward), x 1 KB (backward) | 8 floats | flag
+#define PRJ_LDS_W (8 * 16 * 64 * 4)                  /* floats */
+#define PRJ_PERSIST_LDS ((PRJ_LDS_W + 2 * 3 * 4 * 64 * 4) * 4 + 256)
+
+// Every wave needs ONE round of weight loads in each product and every half-workgroup has at most one block per product
+// (prj_resident, checked on the host; otherwise the layer runs the step loop).  A wave's slices are the same bytes every
+// step, so they are loaded once: Wf's 16 f32x4 per lane stay in registers, W3's in LDS -- the launch streams no weights
+// at all (the step loop: 50 MB per pass at 512 units, from the Infinity Cache).
+template <int NU>
+__global__ __launch_bounds__(PRJ_PT) void prj_persist_fwd_kernel(PrjArgs A, unsigned* sync, int zb, unsigned long long* dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int half = threadIdx.x >> 8, lane = threadIdx.x & 63;
+    f32x4 (*wl)[64] = (f32x4 (*)[64])smem + (threadIdx.x >> 6) * 16;    // this wave's [16][64]
+    f32x4 (*red)[4][64] = (f32x4 (*)[4][64])(smem + PRJ_LDS_W) + half * 3;
+    float* sm = smem + PRJ_LDS_W + 2 * 3 * 4 * 64 * 4;
+    int* flag = (int*)(sm + 8);
+    PRJ_PERSIST_SETUP
+    const int N = A.N, npz = A.ndir * ((A.B + 15) / 16);
+    const int nb_f = (8 * N + 63) / 64, nb_3 = (12 * N + 63) / 64;
+    const int tot_f = nb_f * A.ns_f * npz, tot_3 = nb_3 * A.ns_3 * npz;
+    const int cb = wg % A.B, cd = wg / A.B;          // this workgroup's cell (workgroups >= B ndir have none)
+    const bool cell = wg < A.B * A.ndir;
+    SkinnyArgs Sf, S3;
+    {
+        const float* z[2] = {nullptr, nullptr};
+        prj_sk_args(Sf, A, z, 2 * N, false, 8 * N, A.pf, 2 * N, 8 * N, A.ns_f, zb ? 4 * N : -1, N, 2 * N, false);
+        prj_sk_args(S3, A, z, 2 * N, true, 12 * N, A.p3, N, 12 * N, A.ns_3, -1, 0, 0, false);
+    }
+    // the one block of this half-workgroup in each product
+    const int vb = 2 * wg + half;
+    const bool lf = vb < tot_f, l3 = vb < tot_3;
+    const int bxf = vb % nb_f, byf = (vb / nb_f) % A.ns_f, bzf = vb / (nb_f * A.ns_f);
+    const int bx3 = vb % nb_3, by3 = (vb / nb_3) % A.ns_3, bz3 = vb / (nb_3 * A.ns_3);
+    SkinnyNNCtx cf = skinny_nn_ctx(Sf, bxf, byf, bzf, lf), c3 = skinny_nn_ctx(S3, bx3, by3, bz3, l3);
+    f32x4 wf[16];
+    {
+        f32x4 w3[16];
+        skinny_nn_wload<16>(S3, c3, bz3, c3.g0, w3);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wl[i][lane] = w3[i];
+    }
+    skinny_nn_wload<16>(Sf, cf, bzf, cf.g0, wf);
+    bool ok = true;
+    for (int step = 0; step < A.T && ok; ++step) {
+        int t[2], tp[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            t[k] = A.d[k].reverse ? A.T - 1 - step : step;
+            tp[k] = step == 0 ? -1 : (A.d[k].reverse ? t[k] + 1 : t[k] - 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            Sf.p[k].A = A.d[k].r + ((size_t)(tp[k] < 0 ? 0 : tp[k]) * A.Btot + A.b0) * 2 * N;
+            S3.p[k].A = A.d[k].r + ((size_t)t[k] * A.Btot + A.b0) * 2 * N;
+        }
+        ph = 0;
+        if (step > 0) {                                                 // [tg | a] = r_{t-1} . Wf
+            ok = skinny_nn_pbody<16>(Sf, cf, byf, bzf, [&](int i) { return wf[i]; }, red, lf, waitf);
+            __syncthreads();
+            if (!ok) break;
+            pubf();
+        }
+        ph = 1;
+        if (cell) ok = prj_cell_fwd_pbody<0, NU>(A, cb, cd, cd ? t[1] : t[0], cd ? tp[1] : tp[0], sm, waitf, pubf);
+        else { ok = waitf(); pubf(); }
+        if (!ok) break;
+        ph = 2;
+        {                                                               // scale_outer = r_inner,t . W3 + s
+            ok = skinny_nn_pbody<16>(S3, c3, by3, bz3, [&](int i) { return wl[i][lane]; }, red, l3, waitf);
+            __syncthreads();
+            if (!ok) break;
+            pubf();
+        }
+        ph = 3;
+        if (cell) ok = prj_cell_fwd_pbody<1, NU>(A, cb, cd, cd ? t[1] : t[0], cd ? tp[1] : tp[0], sm, waitf, pubf);
+        else { ok = waitf(); pubf(); }
+    }
+    STAMP_DUMP(dbg, blockIdx.x);
+}
+
+template <int NU>
+__global__ __launch_bounds__(PRJ_PT) void prj_persist_bwd_kernel(PrjArgs A, unsigned* sync, int zb, unsigned long long* dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int half = threadIdx.x >> 8, lane = threadIdx.x & 63;
+    f32x4 (*wl)[64] = (f32x4 (*)[64])smem + (threadIdx.x >> 6) * 16;    // this wave's [16][64]
+    f32x4 (*red)[64] = (f32x4 (*)[64])(smem + PRJ_LDS_W) + half * 3;
+    float* sm = smem + PRJ_LDS_W + 2 * 3 * 4 * 64 * 4;
+    int* flag = (int*)(sm + 8);
+    PRJ_PERSIST_SETUP
+    const int N = A.N, npz = A.ndir * ((A.B + 15) / 16);
+    const int nb_b3 = (N + 15) / 16, nb_bf = (2 * N + 15) / 16;
+    const int tot_b3 = nb_b3 * A.ns_b3 * npz, tot_bf = nb_bf * A.ns_bf * npz;
+    const int cb = wg % A.B, cd = wg / A.B;
+    const bool cell = wg < A.B * A.ndir;
+    SkinnyArgs S3, Sf;
+    {
+        const float* z[2] = {nullptr, nullptr};
+        prj_sk_args(S3, A, z, 12 * N, true, 12 * N, A.pb3, 12 * N, N, A.ns_b3, -1, 0, 0, true);
+        prj_sk_args(Sf, A, z, 8 * N, false, 8 * N, A.pbf, 8 * N, 2 * N, A.ns_bf, zb ? N : -1, 0, 4 * N, true);
+    }
+    const int vb = 2 * wg + half;
+    const bool l3 = vb < tot_b3, lf = vb < tot_bf;
+    const int bx3 = vb % nb_b3, by3 = (vb / nb_b3) % A.ns_b3, bz3 = vb / (nb_b3 * A.ns_b3);
+    const int bxf = vb % nb_bf, byf = (vb / nb_bf) % A.ns_bf, bzf = vb / (nb_bf * A.ns_bf);
+    SkinnyNTCtx c3 = skinny_nt_ctx(S3, bx3, by3, bz3, l3), cf = skinny_nt_ctx(Sf, bxf, byf, bzf, lf);
+    f32x4 wf[16];
+    {
+        f32x4 w3[16];
+        skinny_nt_wload<4>(S3, c3, bz3, c3.c0, w3);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wl[i][lane] = w3[i];
+    }
+    skinny_nt_wload<4>(Sf, cf, bzf, cf.c0, wf);
+    bool ok = true;
+    for (int step = A.T - 1; step >= 0 && ok; --step) {
+        int t[2], tp[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            t[k] = A.d[k].reverse ? A.T - 1 - step : step;
+            tp[k] = step == 0 ? -1 : (A.d[k].reverse ? t[k] + 1 : t[k] - 1);
+        }
+        const bool first = step == A.T - 1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const size_t row0 = (size_t)t[k] * A.Btot + A.b0;
+            S3.p[k].A = A.d[k].dsc + row0 * 12 * N; Sf.p[k].A = A.d[k].dta + row0 * 8 * N;
+        }
+        ph = 0;
+        if (cell) ok = prj_cell_bwd_pbody<1, NU>(A, cb, cd, cd ? t[1] : t[0], cd ? tp[1] : tp[0], first, sm, waitf, pubf);
+        else { ok = waitf(); pubf(); }
+        if (!ok) break;
+        ph = 1;
+        {                                                               // d r_inner,t += d scale_outer . W3^T
+            ok = skinny_nt_pbody<4>(S3, c3, by3, bz3, [&](int i) { return wl[i][lane]; }, red, l3, waitf);
+            __syncthreads();
+            if (!ok) break;
+            pubf();
+        }
+        ph = 2;
+        if (cell) ok = prj_cell_bwd_pbody<0, NU>(A, cb, cd, cd ? t[1] : t[0], cd ? tp[1] : tp[0], first, sm, waitf, pubf);
+        else { ok = waitf(); pubf(); }
+        if (!ok) break;
+        ph = 3;
+        if (step > 0) {                                                 // d r_{t-1} += [d inner gates | d a] . Wf^T
+            ok = skinny_nt_pbody<4>(Sf, cf, byf, bzf, [&](int i) { return wf[i]; }, red, lf, waitf);
+            __syncthreads();
+            if (!ok) break;
+            pubf();
+        }
+    }
+    STAMP_DUMP(dbg, blockIdx.x);
+}
+
+// 0: step loop; otherwise the number of workgroups of the persistent launch (one per CU)
+static int prj_persist_grid() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ASR_PRJ_PERSIST"); on = e ? atoi(e) != 0 : 1; }
+    if (!on) return 0;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 16) return 0;
+    return n;
+}
+
+static int prj_persist_launch(const PrjArgs& A, unsigned* sync, int zb, bool backward, int G, hipStream_t st,
+                              unsigned long long* dbg) {
+    const void* fn;
+    const int N = A.N;
+    if (N > PRJ_PT) return ASR_ERR_LIMIT;
+    fn = backward ? (const void*)prj_persist_bwd_kernel<1> : (const void*)prj_persist_fwd_kernel<1>;
+    if (!scan_grid_fits((size_t)G, PRJ_PERSIST_LDS)) return ASR_ERR_LIMIT;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PRJ_PERSIST_LDS) != hipSuccess) return ASR_ERR_LAUNCH;
+    void* kargs[] = {(void*)&A, (void*)&sync, (void*)&zb, (void*)&dbg};
+    if (hipLaunchKernel(fn, dim3(G), dim3(PRJ_PT), kargs, PRJ_PERSIST_LDS, st) != hipSuccess) return ASR_ERR_LAUNCH;
+    ASR_CHECK_LAUNCH();
+    return ASR_OK;
+}
+
 // Batches of more than PRJ_MAXB rows are run by the caller in chunks (b0 advanced).
 extern "C" int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
     int rc = prj_check(d, ws, ws_bytes);
@@ -422,6 +902,8 @@ extern "C" int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
     PrjArgs& A = H.A;
     const int T = d->T, N = d->N;
     const bool zb = (N % 16) == 0;          // Wf's zero block [0,N) x [4N,8N) in whole 64-column blocks
+    if (hipMemsetAsync(ws, 0, PRJ_SYNC_BYTES, st) != hipSuccess) return ASR_ERR_LAUNCH;
+    if (const int G = prj_use_persist(d->B, N, d->ndir)) return prj_persist_launch(A, (unsigned*)ws, zb ? 1 : 0, false, G, st, prj_dbg(d, ws));
     for (int step = 0; step < T; ++step) {
         prj_times(d, A, step);
         const float *rprev[2], *rrow[2], *Wf[2], *W3[2];
@@ -463,6 +945,8 @@ extern "C" int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
     const bool zb = (N % 16) == 0;
     // carried cell gradients start at zero; dr holds the external part (dhid . W_prj^T) of every step on entry
     if (hipMemsetAsync(A.g_c[0], 0, (size_t)2 * d->ndir * B * N * sizeof(float), st) != hipSuccess) return ASR_ERR_LAUNCH;
+    if (hipMemsetAsync(ws, 0, PRJ_SYNC_BYTES, st) != hipSuccess) return ASR_ERR_LAUNCH;
+    if (const int G = prj_use_persist(d->B, N, d->ndir)) return prj_persist_launch(A, (unsigned*)ws, zb ? 1 : 0, true, G, st, prj_dbg(d, ws));
     for (int step = T - 1; step >= 0; --step) {
         prj_times(d, A, step);
         A.first = step == T - 1;

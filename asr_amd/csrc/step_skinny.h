@@ -197,6 +197,173 @@ static __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyArgs S) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same products as bodies of a PERSISTENT step kernel (raw mode only; step_prjhyper.hip).  What other workgroups of the
+// launch wrote (A) or will read (the partial block) goes through sc1 accesses (scan_common.h's protocol); the weight
+// loads of the first round do not depend on the exchange before the phase, so they are issued BEFORE `waitf()` (the wait
+// for that exchange) and stream in under the phase before; no wave leaves early (the workgroup meets at barriers
+// afterwards); `live` = false: this half-workgroup has no block in this phase and only keeps the barriers company.
+// Products, chains and summation order are those of skinny_nn_kernel / skinny_nt_kernel.
+template <bool P> __device__ __forceinline__ float ldx(const float* p) {
+    if (P) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool P> __device__ __forceinline__ void stx(float* p, float v) {
+    if (P) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+#define SK_OOB 0xfffffff0u      // a buffer offset past every range: the load returns 0
+
+// A wave's slice of W for its first round: the same bytes every step (its block and split are fixed, the weights do
+// not change inside a launch), so a kernel whose waves need one round only may load it ONCE and keep it (registers, LDS).
+struct SkinnyNNCtx { int g0, g1, klo, khi, col, row0, q, bl; bool cv, rv; };
+__device__ __forceinline__ SkinnyNNCtx skinny_nn_ctx(const SkinnyArgs& S, int bx, int by, int bz, bool live) {
+    SkinnyNNCtx c;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    c.q = lane >> 4; c.bl = lane & 15;
+    c.row0 = (bz % S.nchunk) * 16;
+    c.col = bx * 64 + 4 * c.bl;
+    c.cv = c.col < S.Nc; c.rv = c.row0 + c.bl < S.Bm;
+    const bool zb = bx * 64 >= S.zfrom;
+    c.klo = zb ? S.zk0 : 0; c.khi = zb ? S.zk1 : S.K;
+    const int ngrp = (c.khi - c.klo + 3) >> 2, nsl = 4 * S.nsplit;
+    const int per = (ngrp + nsl - 1) / nsl;
+    c.g0 = (by * 4 + wave) * per;
+    c.g1 = live ? min(c.g0 + per, ngrp) : c.g0;
+    return c;
+}
+template <int LD>
+__device__ __forceinline__ void skinny_nn_wload(const SkinnyArgs& S, const SkinnyNNCtx& c, int bz, int g, f32x4 (&w)[LD]) {
+    const SkinnyProb Pb = (bz / S.nchunk) ? S.p[SK_MAXP - 1] : S.p[0];      // SK_MAXP == 2: no dynamic index
+    const float* Wp = Pb.W + c.col;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // k of MFMA step s = 4 i + j for the lanes with MFMA k index q: base + 16 i + 4 q + j, so that a lane's A values of
+    // four steps are 16 contiguous bytes (skinny_nn_pbody loads them as one dwordx4: a quarter of the requests)
+    const int kend = min(c.khi, c.klo + 4 * c.g1);
+#pragma unroll
+    for (int s = 0; s < LD; ++s) {
+        const int k = c.klo + 4 * g + 16 * (s >> 2) + 4 * c.q + (s & 3);
+        w[s] = (k < kend && c.cv) ? *(const f32x4*)(Wp + (size_t)k * S.ldw) : zero;
+    }
+}
+// wget(s): the first round's weights (what skinny_nn_wload(.., g0, w) loads: registers, or read from LDS where they are
+// used); red: 3 slots of [4][64] f32x4 per half-workgroup
+template <int LD, class WGet, class WaitF>
+__device__ __forceinline__ bool skinny_nn_pbody(const SkinnyArgs& S, const SkinnyNNCtx& c, int by, int bz, WGet wget,
+                                                f32x4 (*red)[4][64], bool live, WaitF waitf) {
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const SkinnyProb Pb = (bz / S.nchunk) ? S.p[SK_MAXP - 1] : S.p[0];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {zero, zero, zero, zero};
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc_(Pb.A, (unsigned)S.Bm * (unsigned)S.lda * 4u);
+    const unsigned arow = (unsigned)((c.row0 + c.bl) * S.lda) * 4u;
+    if (!waitf()) return false;
+    {                                                       // ONE round: g1 - g0 <= LD (the host checks)
+        f32x4 a4[LD / 4];
+        const int kend = min(c.khi, c.klo + 4 * c.g1);
+#pragma unroll
+        for (int i = 0; i < LD / 4; ++i) {
+            const int k = c.klo + 4 * c.g0 + 16 * i + 4 * c.q;             // k .. k + 3: steps 4 i .. 4 i + 3
+            a4[i] = ldb_sc1_f4(rsA, (k < kend && c.rv) ? arow + (unsigned)k * 4u : SK_OOB, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < LD; ++s) {
+            const f32x4 ws = wget(s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s >> 2][s & 3], ws[j], acc[j], 0, 0, 0);
+        }
+    }
+    if (wave) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0 && live && c.cv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] + red[0][j][lane] + red[1][j][lane] + red[2][j][lane];
+        const size_t o = ((size_t)by * 16 * S.nchunk + c.row0 + c.q * 4) * S.Nc + c.col;
+        const __amdgpu_buffer_rsrc_t rsC = make_rsrc_(Pb.C, (unsigned)S.nsplit * 16u * S.nchunk * (unsigned)S.Nc * 4u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            st_sc1_f4(rsC, (unsigned)(o + (size_t)r * S.Nc) * 4u, f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]});
+    }
+    return true;
+}
+
+struct SkinnyNTCtx { int c0, c1, klo, khi, kout, row0, q, bl; bool kv, rv; };
+__device__ __forceinline__ SkinnyNTCtx skinny_nt_ctx(const SkinnyArgs& S, int bx, int by, int bz, bool live) {
+    SkinnyNTCtx c;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    c.q = lane >> 4; c.bl = lane & 15;
+    c.row0 = (bz % S.nchunk) * 16;
+    c.kout = bx * 16 + c.bl;
+    c.kv = c.kout < S.Nc; c.rv = c.row0 + c.bl < S.Bm;
+    const bool zb = bx * 16 < S.zfrom;
+    c.klo = zb ? S.zk0 : 0; c.khi = zb ? S.zk1 : S.K;
+    const int nch = (c.khi - c.klo + 63) >> 6, nsl = 4 * S.nsplit;
+    const int per = (nch + nsl - 1) / nsl;
+    c.c0 = (by * 4 + wave) * per;
+    c.c1 = live ? min(c.c0 + per, nch) : c.c0;
+    return c;
+}
+template <int CH>
+__device__ __forceinline__ void skinny_nt_wload(const SkinnyArgs& S, const SkinnyNTCtx& c, int bz, int ch, f32x4 (&wv)[4 * CH]) {
+    const SkinnyProb Pb = (bz / S.nchunk) ? S.p[SK_MAXP - 1] : S.p[0];
+    const float* Wp = Pb.W + (size_t)c.kout * S.ldw + c.klo + 4 * c.q;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int off = (ch + u) * 64 + 16 * e;
+            const bool ok = (ch + u) < c.c1 && c.klo + off + 4 * c.q < c.khi;
+            wv[u * 4 + e] = (ok && c.kv) ? *(const f32x4*)(Wp + off) : zero;
+        }
+    }
+}
+// red: 3 slots of [64] f32x4 per half-workgroup
+template <int CH, class WGet, class WaitF>
+__device__ __forceinline__ bool skinny_nt_pbody(const SkinnyArgs& S, const SkinnyNTCtx& c, int by, int bz, WGet wget,
+                                                f32x4 (*red)[64], bool live, WaitF waitf) {
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const SkinnyProb Pb = (bz / S.nchunk) ? S.p[SK_MAXP - 1] : S.p[0];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = zero, acc1 = zero;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc_(Pb.A, (unsigned)S.Bm * (unsigned)S.lda * 4u);
+    const unsigned aoff = (unsigned)((c.row0 + c.bl) * S.lda + c.klo + 4 * c.q) * 4u;
+    if (!waitf()) return false;
+    {                                                       // ONE round: c1 - c0 <= CH (the host checks)
+        f32x4 av[4 * CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int off = (c.c0 + u) * 64 + 16 * e;
+                const bool ok = (c.c0 + u) < c.c1 && c.klo + off + 4 * c.q < c.khi;
+                av[u * 4 + e] = ldb_sc1_f4(rsA, (ok && c.rv) ? aoff + (unsigned)off * 4u : SK_OOB, 0);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4 * CH; ++v) {
+            const f32x4 ws = wget(v);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][0], ws[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][1], ws[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][2], ws[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v][3], ws[3], acc1, 0, 0, 0);
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && live && c.kv) {
+        acc = acc + red[0][lane] + red[1][lane] + red[2][lane];
+        float* pc = Pb.C + ((size_t)by * 16 * S.nchunk + c.row0 + c.q * 4) * S.Nc + c.kout;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stx<true>(pc + (size_t)r * S.Nc, acc[r]);
+    }
+    return true;
+}
+
 // splits of the reduction axis for a launch of np problems: every wave keeps at least one full round of loads
 static inline int skinny_nsplit(bool nt, int K, int Nc, int np, int target_wgs) {
     const int nblk = nt ? (Nc + 15) / 16 : (Nc + 63) / 64;
@@ -228,13 +395,17 @@ static int skinny(bool nt, SkinnyArgs& S, int np, hipStream_t st) {
     return ASR_OK;
 }
 
+// sum over a workgroup of NW waves (sm: NW floats); every thread of the workgroup calls it
+template <int NW = 4>
 __device__ __forceinline__ float block_sum(float v, float* sm) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
-    return sm[0] + sm[1] + sm[2] + sm[3];
+    float r = sm[0] + sm[1] + sm[2] + sm[3];
+    if (NW == 8) r += sm[4] + sm[5] + sm[6] + sm[7];
+    return r;
 }
 
 #define PRJ_MAXU 8      // units per thread: N <= 2048
