@@ -476,6 +476,33 @@ __device__ __forceinline__ void prj_sk_args(SkinnyArgs& S, const PrjArgs& A, con
 // the saved tensors' stores (21 floats per unit and cell) drain under the phase after.
 #define PRJ_PT 512
 
+// Sum of ns partial blocks in split order, SL loads in flight, every load unconditional (PART_SUM_BEGIN's rule); the
+// number of slots follows ns, so that two splits do not pay four loads.
+template <int SL, class F>
+__device__ __forceinline__ void prj_part_sum_sl(int ns, F f) {
+    for (int sp0 = 0; sp0 < ns; sp0 += SL) {
+#pragma unroll
+        for (int i4 = 0; i4 < SL; ++i4) f(min(sp0 + i4, ns - 1), sp0 + i4 < ns ? 1.f : 0.f);
+    }
+}
+template <class F>
+__device__ __forceinline__ void prj_part_sum(int ns, F f) {
+    if (ns == 1) prj_part_sum_sl<1>(ns, f);
+    else if (ns == 2) prj_part_sum_sl<2>(ns, f);
+    else prj_part_sum_sl<4>(ns, f);
+}
+// two workgroup-wide sums with one pair of barriers (sm: 2 NW floats)
+template <int NW>
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = a; sm[NW + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = sm[0] + sm[1] + sm[2] + sm[3]; b = sm[NW] + sm[NW + 1] + sm[NW + 2] + sm[NW + 3];
+    if (NW == 8) { a += sm[4] + sm[5] + sm[6] + sm[7]; b += sm[NW + 4] + sm[NW + 5] + sm[NW + 6] + sm[NW + 7]; }
+}
+
 // The cells of prj_cell_fwd_kernel / prj_cell_bwd_kernel in that shape (same expressions, same order).
 template <int OUTER, int NU, class WaitF, class PubF>
 __device__ __forceinline__ bool prj_cell_fwd_pbody(const PrjArgs& A, int b, int dir, int t, int tp, float* sm, WaitF waitf,
@@ -508,25 +535,25 @@ __device__ __forceinline__ bool prj_cell_fwd_pbody(const PrjArgs& A, int b, int 
     if (!waitf()) return false;
     if (tp >= 0) {                                   // ---- sums of the partial blocks
         const float* pf = A.pf[dir] + (size_t)b * 8 * N + (OUTER ? 4 * N : 0);
-        PART_SUM_BEGIN(A.ns_f)
+        prj_part_sum(A.ns_f, [&](int sp, float pw) {
             const float* pp = pf + (size_t)sp * A.Bpad * 8 * N;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) rec[u][k] += pw * ldx<true>(pp + k * N + nn[u]);
             }
-        PART_SUM_END
+        });
     }
     if (OUTER) {
         const float* p3 = A.p3[dir] + (size_t)b * 12 * N;
-        PART_SUM_BEGIN(A.ns_3)
+        prj_part_sum(A.ns_3, [&](int sp, float pw) {
             const float* pp = p3 + (size_t)sp * A.Bpad * 12 * N;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) scv[u][k] += pw * ldx<true>(pp + k * N + nn[u]);
             }
-        PART_SUM_END
+        });
     }
     float cn[NU], g4[NU][4];
     float s1 = 0.f;
@@ -624,17 +651,17 @@ __device__ __forceinline__ bool prj_cell_bwd_pbody(const PrjArgs& A, int b, int 
     // total d r_t of this cell: + what the recurrent products hand over (their partial blocks)
     if (!first) {
         const float* pb = A.pbf[dir] + (size_t)b * 2 * N + (OUTER ? N : 0);
-        PART_SUM_BEGIN(A.ns_bf)
+        prj_part_sum(A.ns_bf, [&](int sp, float pw) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) gr[u] += pw * ldx<true>(pb + (size_t)sp * A.Bpad * 2 * N + nn[u]);
-        PART_SUM_END
+        });
     }
     if (!OUTER) {
         const float* pb = A.pb3[dir] + (size_t)b * N;
-        PART_SUM_BEGIN(A.ns_b3)
+        prj_part_sum(A.ns_b3, [&](int sp, float pw) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) gr[u] += pw * ldx<true>(pb + (size_t)sp * A.Bpad * N + nn[u]);
-        PART_SUM_END
+        });
     }
     float dxh[NU], do_[NU], dout[NU];
     float s1 = 0.f, s2 = 0.f;
@@ -648,8 +675,8 @@ __device__ __forceinline__ bool prj_cell_bwd_pbody(const PrjArgs& A, int b, int 
         dxh[u] = dout[u] * al[u];
         s1 += dxh[u]; s2 += dxh[u] * xh[u];
     }
-    const float m1 = block_sum<PRJ_PT / 64>(s1, sm) / N;
-    const float m2 = block_sum<PRJ_PT / 64>(s2, sm) / N;
+    block_sum2<PRJ_PT / 64>(s1, s2, sm);
+    const float m1 = s1 / N, m2 = s2 / N;
     float dg[NU][4], gcn[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -723,7 +750,7 @@ __global__ __launch_bounds__(PRJ_PT) void prj_persist_fwd_kernel(PrjArgs A, unsi
     f32x4 (*wl)[64] = (f32x4 (*)[64])smem + (threadIdx.x >> 6) * 16;    // this wave's [16][64]
     f32x4 (*red)[4][64] = (f32x4 (*)[4][64])(smem + PRJ_LDS_W) + half * 3;
     float* sm = smem + PRJ_LDS_W + 2 * 3 * 4 * 64 * 4;
-    int* flag = (int*)(sm + 8);
+    int* flag = (int*)(sm + 16);
     PRJ_PERSIST_SETUP
     const int N = A.N, npz = A.ndir * ((A.B + 15) / 16);
     const int nb_f = (8 * N + 63) / 64, nb_3 = (12 * N + 63) / 64;
@@ -795,7 +822,7 @@ __global__ __launch_bounds__(PRJ_PT) void prj_persist_bwd_kernel(PrjArgs A, unsi
     f32x4 (*wl)[64] = (f32x4 (*)[64])smem + (threadIdx.x >> 6) * 16;    // this wave's [16][64]
     f32x4 (*red)[64] = (f32x4 (*)[64])(smem + PRJ_LDS_W) + half * 3;
     float* sm = smem + PRJ_LDS_W + 2 * 3 * 4 * 64 * 4;
-    int* flag = (int*)(sm + 8);
+    int* flag = (int*)(sm + 16);
     PRJ_PERSIST_SETUP
     const int N = A.N, npz = A.ndir * ((A.B + 15) / 16);
     const int nb_b3 = (N + 15) / 16, nb_bf = (2 * N + 15) / 16;

@@ -20,6 +20,7 @@ from test_gpu_parity import perturb_params, run_case                # noqa: E402
 
 DEV = 'cuda:0'
 CAP = 1024 if int(os.environ.get('FUZZ_WIDE', '0')) else 64   # width cap of the step-loop and rec families
+FAMILY = os.environ.get('FUZZ_FAMILY', '')
 WIDE = bool(int(os.environ.get('FUZZ_WIDE', '0')))      # widths 320 .. 2048 (with B*T kept small by the rule below)
 
 
@@ -156,6 +157,8 @@ def run(n, seed, only=None):
     for k in range(n):
         p, mk = make_case(rng)
         if only is not None and k not in only:
+            continue
+        if FAMILY and p.get('fam') != FAMILY:                       # FUZZ_FAMILY=prjhyper: only that family's cases
             continue
         tag = ' '.join('%s=%s' % (a, b) for a, b in p.items() if a != 'lengths')
         try:
