@@ -103,6 +103,7 @@ _SIGS = {
     'asr_prjhyper_ws_bytes': (sz, [i32, i32, i32, i32]),
     'asr_prjhyper_fwd': (i32, [C.POINTER(PrjHyperDesc), fp, sz, fp]),
     'asr_prjhyper_bwd': (i32, [C.POINTER(PrjHyperDesc), fp, sz, fp]),
+    'asr_prjhyper_set_mode': (i32, [i32]),
     'asr_scaling_ws_bytes': (sz, [i32, i32, i32, i32]),
     'asr_scaling_fwd': (i32, [C.POINTER(ScalingDesc), fp, sz, fp]),
     'asr_scaling_bwd': (i32, [C.POINTER(ScalingDesc), fp, sz, fp]),

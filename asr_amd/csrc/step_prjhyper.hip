@@ -888,11 +888,14 @@ __global__ __launch_bounds__(PRJ_PT) void prj_persist_bwd_kernel(PrjArgs A, unsi
     STAMP_DUMP(dbg, blockIdx.x);
 }
 
+static int prj_mode_ = 0;
+extern "C" int asr_prjhyper_set_mode(int mode) { const int old = prj_mode_; prj_mode_ = mode ? 1 : 0; return old; }
+
 // 0: step loop; otherwise the number of workgroups of the persistent launch (one per CU)
 static int prj_persist_grid() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("ASR_PRJ_PERSIST"); on = e ? atoi(e) != 0 : 1; }
-    if (!on) return 0;
+    if (!on || prj_mode_) return 0;
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 16) return 0;

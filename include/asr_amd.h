@@ -303,9 +303,17 @@ int asr_hyper_scan_fwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, 
 int asr_hyper_scan_bwd(const asr_hyper_scan_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 
 /* ProjectionHyperLSTMLayer (libs/lasagne_libs/hyper_layers.py:14-523; step :319-417, step_masked
- * :419-456): two N-unit cell-LN LSTMP cells coupled through three scale maps of the new inner hid.  First
- * HIP path: the loop over T runs inside the library, 2 skinny products + 2 cell kernels per step and pass (the
- * products leave per-split partial blocks in the workspace, the cell kernel behind them sums them while loading).
+ * :419-456): two N-unit cell-LN LSTMP cells coupled through three scale maps of the new inner hid.  A step and pass
+ * is 2 skinny products + 2 cells (the products leave per-split partial blocks in the workspace, the cell behind them
+ * sums them while loading).  Two forms, chosen inside the library:
+ *   - ONE persistent launch per pass (round 3): one workgroup of 512 threads per CU, the four phases of a step separated
+ *     by in-kernel exchanges, every wave's slice of the folded weights kept on the chip for the whole sequence (Wf in
+ *     registers, W3 in LDS).  Taken when the slices fit: N <= 512, one round of weight loads per wave at a split into
+ *     2 x CUs blocks, B ndir <= CUs (the reference script's 512 units / 16 rows / both directions do).  Its bounded
+ *     waits report through asr_scan_status(ws, 1) like the scans'.
+ *   - the step loop inside the library (4 launches per step and pass) otherwise, or when ASR_PRJ_PERSIST=0 /
+ *     asr_prjhyper_set_mode(1).
+ * The two differ in how the reduction axes are split (results agree to rounding, not bit for bit).
  * Gate vectors are gate-major [i|f|c|o] here.  One call handles batch rows [b0, b0+B), B <= 64 (every launch carries
  * all 16-row chunks of both directions). */
 typedef struct asr_prjhyper_dir {
@@ -342,6 +350,10 @@ typedef struct asr_prjhyper_desc {
 size_t asr_prjhyper_ws_bytes(int B, int N, int F, int ndir);
 int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+/* 0: the library chooses (default), 1: always the step loop.  Returns the previous mode.  For tests and measurements
+ * (both forms must agree); asr_prjhyper_ws_bytes follows the mode, so query it after the call.  No counterpart in the
+ * reference. */
+int asr_prjhyper_set_mode(int mode);
 
 /* ScalingHyperLSTMLayer with use_peepholes / use_layer_norm / learn_init (libs/lasagne_libs/hyper_layers.py:525-1205;
  * step :963-1095, step_masked :1097-1118, initial rows :1127-1131, scan :1182-1194).  Without options the layer runs on

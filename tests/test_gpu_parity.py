@@ -495,9 +495,19 @@ def test_hyperlhuc_medium():
     run_case(net, b)
 
 
+@pytest.fixture(params=['persistent', 'step_loop'])
+def prj_form(request):
+    """Both forms of asr_prjhyper_*: the persistent launch (the library's choice where the weights fit the chip) and the
+    step loop (wider layers, or asr_prjhyper_set_mode(1))."""
+    from asr_amd import _lib
+    old = _lib.lib().asr_prjhyper_set_mode(1 if request.param == 'step_loop' else 0)
+    yield request.param
+    _lib.lib().asr_prjhyper_set_mode(old)
+
+
 @pytest.mark.parametrize('clip', [0.0, 0.05])
-def test_projection_hyper_small(clip):
-    """ProjectionHyperLSTMLayer (hyper_layers.py:14-523) on the step-loop HIP path + ProjectLSTMLayer on top."""
+def test_projection_hyper_small(clip, prj_form):
+    """ProjectionHyperLSTMLayer (hyper_layers.py:14-523) on both forms of its HIP path + ProjectLSTMLayer on top."""
     from asr_amd.gating_hyper_nets import deep_projection_hyper_model
     out = deep_projection_hyper_model(None, None, 5, 6, 2, 4, 8, grad_clipping=clip, device=_dev(), seed=61)
     net, inner = out[0], out[1:]
@@ -615,13 +625,48 @@ def test_projection_hyper_aux_costs_and_trainer():
     assert abs(out[0] - os_ / b['mask'].sum()) < 1e-4 * max(1.0, os_ / b['mask'].sum())
 
 
-def test_projection_hyper_medium():
+def test_projection_hyper_medium(prj_form):
     """B = 18 (two batch chunks), N = 64, F = 32."""
     from asr_amd.gating_hyper_nets import deep_projection_hyper_model
     net = deep_projection_hyper_model(None, None, 11, 13, 2, 32, 64, grad_clipping=1.0, device=_dev(), seed=64)[0]
     perturb_params(net, 65, 0.03)
     b = make_batch(np.random.default_rng(66), 18, 21, 11, 13)
     run_case(net, b, calibrate=True)
+
+
+@pytest.mark.parametrize('shape', [(3, 7, 8, 4), (16, 33, 64, 32), (5, 19, 132, 20), (40, 9, 36, 12), (16, 12, 512, 256)])
+def test_projection_hyper_persistent_launch_agrees_with_the_step_loop(shape):
+    """The persistent launch (weights resident in registers and LDS, phases separated by in-kernel exchanges) against the
+    step loop on the same network and batch: posteriors and every gradient to rounding (the two split the reduction axes
+    differently, so not bit for bit), twice in a row (the launch's sync block and partial buffers are reused), and the
+    persistent form reproduces itself bit for bit.  The last shape is the reference script's width."""
+    from asr_amd import _lib
+    from asr_amd.gating_hyper_nets import deep_projection_hyper_model
+    B, T, N, F = shape
+    L = _lib.lib()
+    net = deep_projection_hyper_model(None, None, 9, 11, 2, F, N, grad_clipping=1.0, device=_dev(), seed=71)[0]
+    perturb_params(net, 72, 0.03)
+    b = make_batch(np.random.default_rng(73), B, T, 9, 11)
+    x, m, y = (torch.from_numpy(np.ascontiguousarray(b[k])).to(_dev()) for k in ('x', 'mask', 'y'))
+
+    def run():
+        ce = net.loss(x, m, y, m, None, train=True)[0]
+        net.backward(); net.join_deferred(); net.check_status()
+        return float(ce), net.get_all_grad_values()
+
+    old = L.asr_prjhyper_set_mode(1)
+    try:
+        l_loop, g_loop = run()
+        L.asr_prjhyper_set_mode(0)
+        l_per, g_per = run()
+        l_per2, g_per2 = run()
+    finally:
+        L.asr_prjhyper_set_mode(old)
+    assert l_per == l_per2 and all(np.array_equal(a, c) for a, c in zip(g_per, g_per2))
+    assert abs(l_per - l_loop) <= 2e-5 * max(1.0, abs(l_loop))
+    num = sum(float(((a.astype(np.float64) - c) ** 2).sum()) for a, c in zip(g_per, g_loop))
+    den = sum(float((c.astype(np.float64) ** 2).sum()) for c in g_loop)
+    assert (num / den) ** 0.5 < 2e-5, (num / den) ** 0.5
 
 
 def test_adam_step_matches_oracle():
