@@ -85,7 +85,13 @@ def run_case(net, batch, cond_key=None, context=0, tol_f=2e-5, tol_g=1e-4, gscal
                                                  batch.get(cond_key), context=context)
     assert abs(ce.item() - os_) / abs(os_) < tol_f, (ce.item(), os_)
     tm = batch['mask'] if not context else batch['mask'][:, :context]
-    assert ((pred.cpu().numpy() == opred) | (tm == 0)).all()
+    bad = (pred.cpu().numpy() != opred) & (tm != 0)
+    if bad.any():
+        # a frame whose two best classes the float64 oracle itself holds closer than twice the forward bound may fall
+        # either way; any other disagreement is an error
+        op = opost if not context else opost[:, :context]
+        top2 = np.sort(op, axis=2)[:, :, -2:]
+        assert ((top2[..., 1] - top2[..., 0])[bad] < 2.0 * tol_f * np.max(np.abs(opost))).all(), 'opred'
     grads = net.get_all_grad_values()
     names = [n for n, _ in net.param_names_shapes()]
     worst = 0.0
