@@ -62,7 +62,10 @@ cases += [('LSTMP options 2x512', 1, lambda: G._build_rec(123, 61, 2, 512, 1.0, 
           ('LSTM 1x2048 streamed', 1, lambda: builders.build_deep_lstm(None, None, 123, 1, 2048, 0, 61, 1.0, False, False, 0,
                                                                        device=dev, seed=1), max(reps // 2, 4))]
 bad = 0
+only = os.environ.get('SOAK_ONLY', '')          # substring of a case name: only those cases
 for name, cfg, mk, n in cases:
+    if only and only not in name:
+        continue
     net = mk()
     steploop = name.startswith(('ProjectionHyper', 'ScalingHyper options'))
     teams = '(teams)' in name
