@@ -107,6 +107,7 @@ _SIGS = {
     'asr_scaling_ws_bytes': (sz, [i32, i32, i32, i32]),
     'asr_scaling_fwd': (i32, [C.POINTER(ScalingDesc), fp, sz, fp]),
     'asr_scaling_bwd': (i32, [C.POINTER(ScalingDesc), fp, sz, fp]),
+    'asr_scaling_set_mode': (i32, [i32]),
     'asr_opt_step': (i32, [i32, fp, fp, fp, fp, sz, f32, f32, f32, f32, fp, fp]),
     'asr_norm_clip_mult': (i32, [fp, f32, f32, fp, fp]),
     'asr_lstm_pack_floats': (sz, [i32, i32]),

@@ -746,7 +746,10 @@ __device__ __forceinline__ bool prj_cell_bwd_pbody(const PrjArgs& A, int b, int 
 template <int NU>
 __global__ __launch_bounds__(PRJ_PT) void prj_persist_fwd_kernel(PrjArgs A, unsigned* sync, int zb, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int half = threadIdx.x >> 8, lane = threadIdx.x & 63;
+    // wave-uniform values the compiler must know to be uniform: the product bodies build buffer descriptors from the
+    // (direction-selected) operand pointers, and a descriptor from a value it takes to be divergent costs a waterfall
+    // loop around every load and store
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), lane = threadIdx.x & 63;
     f32x4 (*wl)[64] = (f32x4 (*)[64])smem + (threadIdx.x >> 6) * 16;    // this wave's [16][64]
     f32x4 (*red)[4][64] = (f32x4 (*)[4][64])(smem + PRJ_LDS_W) + half * 3;
     float* sm = smem + PRJ_LDS_W + 2 * 3 * 4 * 64 * 4;
@@ -818,7 +821,10 @@ __global__ __launch_bounds__(PRJ_PT) void prj_persist_fwd_kernel(PrjArgs A, unsi
 template <int NU>
 __global__ __launch_bounds__(PRJ_PT) void prj_persist_bwd_kernel(PrjArgs A, unsigned* sync, int zb, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int half = threadIdx.x >> 8, lane = threadIdx.x & 63;
+    // wave-uniform values the compiler must know to be uniform: the product bodies build buffer descriptors from the
+    // (direction-selected) operand pointers, and a descriptor from a value it takes to be divergent costs a waterfall
+    // loop around every load and store
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), lane = threadIdx.x & 63;
     f32x4 (*wl)[64] = (f32x4 (*)[64])smem + (threadIdx.x >> 6) * 16;    // this wave's [16][64]
     f32x4 (*red)[64] = (f32x4 (*)[64])(smem + PRJ_LDS_W) + half * 3;
     float* sm = smem + PRJ_LDS_W + 2 * 3 * 4 * 64 * 4;

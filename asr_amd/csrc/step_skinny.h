@@ -219,7 +219,7 @@ template <bool P> __device__ __forceinline__ void stx(float* p, float v) {
 struct SkinnyNNCtx { int g0, g1, klo, khi, col, row0, q, bl; bool cv, rv; };
 __device__ __forceinline__ SkinnyNNCtx skinny_nn_ctx(const SkinnyArgs& S, int bx, int by, int bz, bool live) {
     SkinnyNNCtx c;
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
     c.q = lane >> 4; c.bl = lane & 15;
     c.row0 = (bz % S.nchunk) * 16;
     c.col = bx * 64 + 4 * c.bl;
@@ -251,7 +251,7 @@ __device__ __forceinline__ void skinny_nn_wload(const SkinnyArgs& S, const Skinn
 template <int LD, class WGet, class WaitF>
 __device__ __forceinline__ bool skinny_nn_pbody(const SkinnyArgs& S, const SkinnyNNCtx& c, int by, int bz, WGet wget,
                                                 f32x4 (*red)[4][64], bool live, WaitF waitf) {
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
     const SkinnyProb Pb = (bz / S.nchunk) ? S.p[SK_MAXP - 1] : S.p[0];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4] = {zero, zero, zero, zero};
@@ -266,6 +266,7 @@ __device__ __forceinline__ bool skinny_nn_pbody(const SkinnyArgs& S, const Skinn
             const int k = c.klo + 4 * c.g0 + 16 * i + 4 * c.q;             // k .. k + 3: steps 4 i .. 4 i + 3
             a4[i] = ldb_sc1_f4(rsA, (k < kend && c.rv) ? arow + (unsigned)k * 4u : SK_OOB, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);                  // every load in flight before the first MFMA (hipcc sinks them otherwise)
 #pragma unroll
         for (int s = 0; s < LD; ++s) {
             const f32x4 ws = wget(s);
@@ -293,7 +294,7 @@ __device__ __forceinline__ bool skinny_nn_pbody(const SkinnyArgs& S, const Skinn
 struct SkinnyNTCtx { int c0, c1, klo, khi, kout, row0, q, bl; bool kv, rv; };
 __device__ __forceinline__ SkinnyNTCtx skinny_nt_ctx(const SkinnyArgs& S, int bx, int by, int bz, bool live) {
     SkinnyNTCtx c;
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
     c.q = lane >> 4; c.bl = lane & 15;
     c.row0 = (bz % S.nchunk) * 16;
     c.kout = bx * 16 + c.bl;
@@ -325,7 +326,7 @@ __device__ __forceinline__ void skinny_nt_wload(const SkinnyArgs& S, const Skinn
 template <int CH, class WGet, class WaitF>
 __device__ __forceinline__ bool skinny_nt_pbody(const SkinnyArgs& S, const SkinnyNTCtx& c, int by, int bz, WGet wget,
                                                 f32x4 (*red)[64], bool live, WaitF waitf) {
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
     const SkinnyProb Pb = (bz / S.nchunk) ? S.p[SK_MAXP - 1] : S.p[0];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc0 = zero, acc1 = zero;
@@ -343,6 +344,7 @@ __device__ __forceinline__ bool skinny_nt_pbody(const SkinnyArgs& S, const Skinn
                 av[u * 4 + e] = ldb_sc1_f4(rsA, (ok && c.rv) ? aoff + (unsigned)off * 4u : SK_OOB, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                  // every load in flight before the first MFMA
 #pragma unroll
         for (int v = 0; v < 4 * CH; ++v) {
             const f32x4 ws = wget(v);

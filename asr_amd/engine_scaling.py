@@ -330,6 +330,9 @@ class ScalingStepPair(object):
             desc.b0 = b0; desc.B = min(64, B - b0)
             check(fn(C.byref(desc), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
                   'asr_scaling_%s' % ('bwd' if backward else 'fwd'))
+        # the persistent launch's sync block heads the workspace: Network.check_status reads its abort word
+        self.net._last_groups = getattr(self.net, '_last_groups', {})
+        self.net._last_groups[('scaling', self.idx)] = 1
 
     def forward(self, X, T, B, mask, cond, train):
         N, H = self.N, self.H

@@ -403,6 +403,12 @@ typedef struct asr_scaling_desc {
 size_t asr_scaling_ws_bytes(int B, int N, int H, int ndir);
 int asr_scaling_fwd(const asr_scaling_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
 int asr_scaling_bwd(const asr_scaling_desc* d, void* ws, size_t ws_bytes, asr_stream_t stream);
+/* Like asr_prjhyper_*, the library runs this recurrence as ONE persistent launch per pass where the shape allows (both
+ * unit counts <= 512, B ndir <= CUs, the blocks of a product phase within 2 x CUs: the TIMIT script's 64 / 128 units do)
+ * and as the step loop otherwise; ASR_SCAL_PERSIST=0 or asr_scaling_set_mode(1) force the step loop (0: the library
+ * chooses; returns the previous mode; asr_scaling_ws_bytes does not depend on it).  A bounded wait of the persistent launch
+ * that gave up is reported by asr_scan_status(ws, 1).  No counterpart in the reference. */
+int asr_scaling_set_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -387,11 +387,20 @@ def test_scaling_hyper_reference_widths():
     run_case(net, b, calibrate=True)
 
 
+@pytest.fixture(params=['persistent', 'step_loop'])
+def scal_form(request):
+    """Both forms of asr_scaling_*: the persistent launch (the library's choice where the shape allows) and the step loop."""
+    from asr_amd import _lib
+    old = _lib.lib().asr_scaling_set_mode(1 if request.param == 'step_loop' else 0)
+    yield request.param
+    _lib.lib().asr_scaling_set_mode(old)
+
+
 @pytest.mark.parametrize('peep,ln,li', [(True, False, False), (False, True, False), (False, False, True), (True, True, True)])
 @pytest.mark.parametrize('clip', [0.0, 0.05])
-def test_scaling_hyper_options_small(peep, ln, li, clip):
+def test_scaling_hyper_options_small(peep, ln, li, clip, scal_form):
     """use_peepholes / use_layer_norm / learn_init of ScalingHyperLSTMLayer (hyper_layers.py:977-1091,:1127-1131) on
-    the step-loop path of step_scaling.hip: two stacked bidirectional layers, ragged lengths, clip biting."""
+    both forms of step_scaling.hip's path: two stacked bidirectional layers, ragged lengths, clip biting."""
     from asr_amd.gating_hyper_nets import deep_scaling_hyper_model
     net = deep_scaling_hyper_model(None, None, 5, 6, [8, 4], [12, 8], use_peepholes=peep, use_layer_norm=ln,
                                    learn_init=li, grad_clipping=clip, device=_dev(), seed=51)
@@ -402,7 +411,7 @@ def test_scaling_hyper_options_small(peep, ln, li, clip):
 
 @pytest.mark.parametrize('peep,ln', [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize('clip', [0.0, 0.05])
-def test_equal_scale_hyper_small(peep, ln, clip):
+def test_equal_scale_hyper_small(peep, ln, clip, scal_form):
     """EqualScaleHyperLSTMLayer (hyper_layers.py:1207-1890): the scaling layer's step with an inner cell as wide as the outer
     one and its hidden state projected to the inner units; two stacked bidirectional layers, ragged lengths.  The kernels
     run the projection folded into its consumers (engine_scaling.EqualScaleStepPair), the oracle runs it as written."""
@@ -414,7 +423,7 @@ def test_equal_scale_hyper_small(peep, ln, clip):
     run_case(net, b)
 
 
-def test_equal_scale_hyper_medium_inner_hid_and_limits():
+def test_equal_scale_hyper_medium_inner_hid_and_limits(scal_form):
     """64 outer / 16 inner units, 18 rows (two batch chunks), T = 29, every option; the projected inner hidden sequences of
     get_inner_hid=True against the oracle's (with learn_init: the reverse direction's padding holds inner_hid_init)."""
     from asr_amd.gating_hyper_nets import deep_equal_scale_hyper_model
@@ -436,7 +445,7 @@ def test_equal_scale_hyper_medium_inner_hid_and_limits():
 
 @pytest.mark.parametrize('peep,ln', [(False, False), (True, True)])
 @pytest.mark.parametrize('clip', [0.0, 0.05])
-def test_equal_scale_hyper_learn_init(peep, ln, clip):
+def test_equal_scale_hyper_learn_init(peep, ln, clip, scal_form):
     """learn_init=True (hyper_layers.py:1782-1788): inner_hid_init is a row of the projected space; two stacked
     bidirectional layers, ragged lengths (the reverse direction starts on padding)."""
     from asr_amd.gating_hyper_nets import deep_equal_scale_hyper_model
@@ -461,7 +470,7 @@ def test_step_loop_layers_more_rows_than_one_call():
     run_case(net, b)
 
 
-def test_scaling_hyper_options_timit_script_shape():
+def test_scaling_hyper_options_timit_script_shape(scal_form):
     """The configuration scripts/timit/exp_scalehyper.py runs (:26-41,:331-338): one bidirectional layer, 64 inner /
     128 outer units, layer norm and learned initial rows, 123 inputs, 63 classes; 18 rows = two batch chunks; the
     inner hidden sequences of get_inner_hid=True against the oracle's."""
