@@ -347,6 +347,22 @@ static PrjSplits prj_splits(int B, int N, int ndir) {
     const int pg = prj_use_persist(B, N, ndir);
     return prj_splits_tw(B, N, ndir, pg ? 2 * pg : prj_target_wgs());
 }
+// The grid of the persistent launch: as many workgroups as its widest phase has work for (a cell each, two product
+// blocks each), not the whole chip -- a small layer leaves the other CUs to whatever else runs on the GPU (two
+// full-chip persistent grids of two processes can never be co-resident and would wait for each other until their
+// deadlines; grids that fit side by side cannot).
+static int prj_persist_wgs(int B, int N, int ndir, int cus) {
+    const PrjSplits s = prj_splits_tw(B, N, ndir, 2 * cus);
+    const int npz = ndir * ((B + 15) / 16);
+    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    int m = cdiv(8 * N, 64) * s.f;
+    m = m > cdiv(12 * N, 64) * s.w3 ? m : cdiv(12 * N, 64) * s.w3;
+    m = m > cdiv(N, 16) * s.b3 ? m : cdiv(N, 16) * s.b3;
+    m = m > cdiv(2 * N, 16) * s.bf ? m : cdiv(2 * N, 16) * s.bf;
+    int g = cdiv(m * npz, 2);
+    if (g < B * ndir) g = B * ndir;
+    return g < cus ? g : cus;
+}
 static size_t prj_part_floats(int B, int N, int ndir) {
     const PrjSplits s = prj_splits(B, N, ndir);
     const size_t bp = (size_t)((B + 15) / 16) * 16;
@@ -939,7 +955,8 @@ extern "C" int asr_prjhyper_fwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
     const int T = d->T, N = d->N;
     const bool zb = (N % 16) == 0;          // Wf's zero block [0,N) x [4N,8N) in whole 64-column blocks
     if (hipMemsetAsync(ws, 0, PRJ_SYNC_BYTES, st) != hipSuccess) return ASR_ERR_LAUNCH;
-    if (const int G = prj_use_persist(d->B, N, d->ndir)) return prj_persist_launch(A, (unsigned*)ws, zb ? 1 : 0, false, G, st, prj_dbg(d, ws));
+    if (const int cus = prj_use_persist(d->B, N, d->ndir))
+        return prj_persist_launch(A, (unsigned*)ws, zb ? 1 : 0, false, prj_persist_wgs(d->B, N, d->ndir, cus), st, prj_dbg(d, ws));
     for (int step = 0; step < T; ++step) {
         prj_times(d, A, step);
         const float *rprev[2], *rrow[2], *Wf[2], *W3[2];
@@ -982,7 +999,8 @@ extern "C" int asr_prjhyper_bwd(const asr_prjhyper_desc* d, void* ws, size_t ws_
     // carried cell gradients start at zero; dr holds the external part (dhid . W_prj^T) of every step on entry
     if (hipMemsetAsync(A.g_c[0], 0, (size_t)2 * d->ndir * B * N * sizeof(float), st) != hipSuccess) return ASR_ERR_LAUNCH;
     if (hipMemsetAsync(ws, 0, PRJ_SYNC_BYTES, st) != hipSuccess) return ASR_ERR_LAUNCH;
-    if (const int G = prj_use_persist(d->B, N, d->ndir)) return prj_persist_launch(A, (unsigned*)ws, zb ? 1 : 0, true, G, st, prj_dbg(d, ws));
+    if (const int cus = prj_use_persist(d->B, N, d->ndir))
+        return prj_persist_launch(A, (unsigned*)ws, zb ? 1 : 0, true, prj_persist_wgs(d->B, N, d->ndir, cus), st, prj_dbg(d, ws));
     for (int step = T - 1; step >= 0; --step) {
         prj_times(d, A, step);
         A.first = step == T - 1;

@@ -988,7 +988,14 @@ static int scal_use_persist(int B, int N, int H, int ndir) {
     auto cd = [](int a, int b) { return (a + b - 1) / b; };
     const int f0 = (cd(4 * H, 64) * s.tg + cd(4 * N, 64) * s.a) * npz, f2 = cd(16 * N, 64) * s.sc * npz;
     const int b1 = cd(H, 16) * s.b1 * npz, b3 = (cd(W, 16) * s.gh + cd(N, 16) * s.go) * npz;
-    return (f0 <= 2 * g && f2 <= 2 * g && b1 <= 2 * g && b3 <= 2 * g) ? g : 0;
+    if (!(f0 <= 2 * g && f2 <= 2 * g && b1 <= 2 * g && b3 <= 2 * g)) return 0;
+    // as many workgroups as the widest phase has work for (a cell each, two product blocks each), not the whole chip: a
+    // small layer leaves the other CUs to whatever else runs on the GPU (step_prjhyper.hip, prj_persist_wgs)
+    int m = f0 > f2 ? f0 : f2;
+    m = m > b1 ? m : b1; m = m > b3 ? m : b3;
+    int w = cd(m, 2);
+    if (w < B * ndir) w = B * ndir;
+    return w < g ? w : g;
 }
 #define SCP_SYNC_BYTES ((size_t)((SYNC_STRIDE * 4 + 255) / 256) * 256)
 static size_t scal_part_floats(int B, int N, int H, int ndir) {

@@ -50,7 +50,7 @@ full = (b['x'], b['mask'], None, None, b['y'], b['mask'])
 ref, fi, _ = mkp()
 ref.loss(t(full[0]), t(full[1]), t(full[4]), t(full[5]), None, train=True)
 c_ref = fi.pair.aux_costs(0.7, 1.3).tolist()
-ref.backward(); torch.cuda.synchronize()
+ref.backward(); torch.cuda.synchronize(); ref.check_status()
 g_ref = [g.copy() for g in ref.get_all_grad_values()]
 net, fi, _ = mkp()
 ar = dp.GradAllReduce(net)

@@ -1,5 +1,6 @@
 """Step time of deep_scaling_hyper_model at the shape of scripts/timit/exp_scalehyper.py (one bidirectional layer,
-64 inner / 128 outer units, layer norm + learned initial rows, batch 32) -- the step-loop path (diagnostic)."""
+64 inner / 128 outer units, layer norm + learned initial rows, batch 32): the option path (persistent launch, or the step
+loop with ASR_SCAL_PERSIST=0) beside the option-free layer on the persistent HyperLSTM scan (diagnostic)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
