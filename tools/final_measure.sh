@@ -24,8 +24,9 @@ for l in open('$O/${TAG}_other_configs.jsonl'):
     d=json.loads(l); print(d['config']['workload'][:40], d['config']['per_gpu_batch'], round(d['value']), round(d['ms_per_step'],1))";;
   soak)    timeout -k 10 1000 python -u tools/soak_determinism.py 40 > $O/${TAG}_soak_determinism.log 2>&1; rc=$?; tail -20 $O/${TAG}_soak_determinism.log; exit $rc;;
   dp)      : > $O/${TAG}_dp_gpu_check.log
-           for ov in 1 0; do echo "== ASR_DP_OVERLAP=$ov" >> $O/${TAG}_dp_gpu_check.log
-             ASR_DP_OVERLAP=$ov timeout -k 10 300 python -u -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29533 + ov)) tools/dp_gpu_check.py >> $O/${TAG}_dp_gpu_check.log 2>&1 || { tail -8 $O/${TAG}_dp_gpu_check.log; exit 1; }; done
-           grep -v "^W\|^\*" $O/${TAG}_dp_gpu_check.log | tail -12;;
+           # two processes on the one GPU, gloo: bounded (a run that stalls is killed after 120 s) and printing as it goes
+           for ov in 1 0; do echo "== ASR_DP_OVERLAP=$ov" | tee -a $O/${TAG}_dp_gpu_check.log
+             ASR_DP_OVERLAP=$ov timeout -k 10 120 python -u -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29533 + ov)) tools/dp_gpu_check.py 2>&1 | grep -v "^W1\|^\[W\|^\*\*\*\|amdgpu.ids" | tee -a $O/${TAG}_dp_gpu_check.log
+             [ ${PIPESTATUS[0]} -eq 0 ] || exit 1; done;;
   *) echo "usage: $0 suite|bench|sweep|configs|soak|dp"; exit 2;;
 esac
