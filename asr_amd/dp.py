@@ -17,7 +17,8 @@ class GradAllReduce(object):
         net.world = self.world
         net.dropout_rank = dist.get_rank(group) if dist.is_initialized() else 0   # every rank its own masks
         self.cuda = net.device.type == 'cuda'
-        self.stream = torch.cuda.Stream(device=net.device) if self.cuda else None
+        self.third_stream = os.environ.get('ASR_DP_STREAM', '0') == '1'
+        self.stream = torch.cuda.Stream(device=net.device) if (self.cuda and self.third_stream) else None
         self.pending = []
         # ASR_DP_OVERLAP=0: no bucket leaves before the last BPTT scan has finished; finish() then reduces the whole
         # flat gradient in one collective on the main stream.  The fallback for a node on which RCCL's kernels and the
@@ -32,10 +33,18 @@ class GradAllReduce(object):
             net.grad_hook = self.bucket_ready
 
     def bucket_ready(self, lo, hi):
+        # Called inside Network.deferred(): the current stream is the network's side stream, behind this bucket's
+        # parameter-gradient GEMMs.  The collective is issued on THAT stream (ASR_DP_STREAM=1: on a third stream behind
+        # an event, the round-2 form).  With a third stream the two-process rehearsal (tools/dp_gpu_check.py, gloo)
+        # stalled in finish(), both ranks waiting for a bucket's collective, in 2 of 8 and 4 of 8 runs on two boxes at
+        # HIP's default of 4 hardware queues per process, in 0 of 8 with GPU_MAX_HW_QUEUES=16, and in 0 of 16 with the
+        # collective on the side stream (tools/dp_repeat.sh): no more streams than hardware queues
+        # is the robust form, and a bucket's all-reduce in front of the next layer's parameter-gradient GEMMs costs
+        # them at most its own duration.
         g = self.net.store.g[lo:hi]
-        if self.cuda:
+        if self.cuda and self.third_stream:
             ev = torch.cuda.Event()
-            ev.record()                           # gradients of this bucket are enqueued on main
+            ev.record()
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 self.pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group,
@@ -52,7 +61,7 @@ class GradAllReduce(object):
         for w in self.pending:
             w.wait()
         self.pending = []
-        if self.cuda:
+        if self.cuda and self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 
     def disable_overlap(self):

@@ -3,8 +3,9 @@ all-reduce launched from the deferred side stream, loss scaled by 1/B_global) ag
 batch run in one process.  Backend gloo (two ranks cannot share one device under RCCL); the networks
 are tiny, so both ranks' persistent scans (2 workgroups each) are trivially co-resident.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_gpu_check.py"""
-import os, sys
+import faulthandler, os, sys
 import numpy as np
+faulthandler.dump_traceback_later(60, exit=True)      # a stalled rank says where it stands and leaves (normal run: 3 s)
 import torch
 import torch.distributed as dist
 
