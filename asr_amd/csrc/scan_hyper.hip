@@ -216,7 +216,10 @@ __global__ __launch_bounds__(256 * NC) void hyper_scan_fwd_kernel(HyperArgs A, s
     float* Wm = smem;                                           // [KSP/4][64][4]
     float* Wg = Wm + (size_t)KSP * 64;                          // [(KSP+HSP)/4][4][CR][4]
     float* Wd = Wg + (size_t)(KSP + HSP) * 4 * CR;              // [3][HSP/4][64][4]
-    const int team = threadIdx.x >> 8;                          // wave-uniform
+    // wave-uniform, and the compiler must KNOW it: the exchange buffers' descriptors are built from pointers that depend
+    // on it, and a descriptor from a value taken to be divergent costs a waterfall loop (4 v_readfirstlane, 2 v_cmp, a
+    // saveexec and a branch) around every buffer load and store of the step
+    const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     float* red = Wd + (size_t)3 * HSP * 64 + (size_t)team * 3 * 4 * 256;   // per team [3 tiles][4 waves][64][4]
     int* flag = (int*)(Wd + (size_t)3 * HSP * 64 + (size_t)NC * 3 * 4 * 256);
 
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256 * NC) void hyper_scan_bwd_kernel(HyperArgs A, s
     float* Wt = smem;                                   // [4 waves][NBW][64][4]
     float* Mb = Wt + (size_t)A.NBW * 1024;              // [HT][3][64][4]
     float* Rw = Mb + (size_t)HT * 3 * 256;              // [S4P/4][4][4+UH][4]
-    const int team = threadIdx.x >> 8;                  // which of the NC chunks this 4-wave team carries (see forward)
+    const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   // which of the NC chunks this 4-wave team carries (see forward)
     float* stage = Rw + (size_t)S4P * 4 * (4 + UH);     // per team: HYPER_BWD_STAGE floats
     float* dal = stage + (size_t)team * HYPER_BWD_STAGE;          // [16 cols][16 b]            da
     float* dDl = dal + 256;                             // [3][16 cols][16 b]         dD

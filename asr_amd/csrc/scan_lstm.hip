@@ -234,7 +234,7 @@ __device__ __forceinline__ void combine_sums4(const float* st, int KS, int tid, 
 // hyper_scan_fwd_kernel, scan_hyper.hip).  Roles (K quarter, epilogue duty) are rotated per team so that the teams'
 // epilogue waves sit on different SIMDs.  Per-row results do not depend on NC.
 #define TEAM_IDS_(NC_)                                                                                   \
-    const int team = threadIdx.x >> 8;                                                                   \
+    const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   /* uniform, and known to be: scan_hyper.hip */ \
     const int j = blockIdx.x, dir = blockIdx.y, chunk = blockIdx.z * NC_ + team + A.chunk0;              \
     const int grp = chunk * A.ndir + dir;                                 /* exchange buffers: per chunk */ \
     const int sgrp = (blockIdx.z * NC_ + A.chunk0) * A.ndir + dir;        /* arrival counters: per workgroup set */ \
